@@ -1,0 +1,259 @@
+"""ctypes front-end of the CPU checker (oracle/mpc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under mpc_amd/ imports this module.
+
+The controller set-up restated here (tyre stiffness, cost matrices, DARE
+terminal weight) follows LMPC2.py:98-112,220-260,349-440, OFLMPC2.py:274-279
+and LPVMPC.py:191-226 of the reference.  QP parity is unpinned (see the header
+of mpc_oracle.c).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.linalg
+import yaml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+KIND = {"L": 0, "OFL": 1, "LPV": 2}
+CFG_LEN = 55
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force: bool = False) -> None:
+    """Compile both precisions of the checker with gcc (a few seconds)."""
+    if force or not all(os.path.exists(os.path.join(_BUILD, f"liboracle_{p}.so")) for p in ("f64", "f80")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Oracle:
+    """One precision of the checker: 'f64' (double) or 'f80' (x87 long double)."""
+
+    def __init__(self, precision: str = "f64"):
+        path = os.path.join(_BUILD, f"liboracle_{precision}.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        L.orc_real_bytes.restype = C.c_int
+        L.orc_tyre_stiffness.argtypes = [C.c_double, C.c_double, _dp]
+        L.orc_plant_f.argtypes = [_dp, C.c_double, C.c_int, _dp, _dp]
+        L.orc_plant_rk4.argtypes = [_dp, C.c_double, C.c_double, C.c_int, _dp]
+        L.orc_ekf_jacobian.argtypes = [_dp, C.c_double, _dp, _dp]
+        L.orc_ekf_time_update.argtypes = [_dp, _dp, C.c_double, C.c_double, _dp, _dp]
+        L.orc_ekf_meas_update.argtypes = [_dp, _dp, _dp, _dp]
+        L.orc_skidpad_waypoints.argtypes = [C.c_double] * 3 + [C.c_int, _dp, C.c_double, C.c_int, C.c_double, _dp, _dp]
+        L.orc_skidpad_waypoints.restype = C.c_double
+        L.orc_step_waypoints.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, _dp, _dp, _dp]
+        L.orc_step_waypoints.restype = C.c_double
+        L.orc_mpc_optimize.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
+                                       C.c_double, C.c_int]
+        L.orc_mpc_optimize.restype = C.c_int
+        L.orc_skidpad_step.argtypes = [_dp, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
+                                       C.c_int]
+        L.orc_skidpad_step.restype = C.c_int
+        L.orc_skidpad_run.argtypes = [_dp, _dp, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, C.c_double, C.c_double,
+                                      C.c_int]
+        L.orc_skidpad_run.restype = C.c_long
+        self.precision = precision
+        # default solver tolerances: as tight as the arithmetic allows
+        self.tol = (1e-13, 1e-10, 100) if precision == "f64" else (1e-17, 1e-14, 200)
+
+    # -- set-up ---------------------------------------------------------
+    def tyre_stiffness(self, m, x_cg):
+        out = np.zeros(2)
+        self.lib.orc_tyre_stiffness(float(m), float(x_cg), _ptr(out))
+        return float(out[0]), float(out[1])
+
+    # -- plant / EKF ----------------------------------------------------
+    def plant_f(self, x, u, mp):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        self.lib.orc_plant_f(_ptr(x), float(u), len(x), _ptr(np.ascontiguousarray(mp, dtype=np.float64)), _ptr(out))
+        return out
+
+    def plant_rk4(self, x, u, dt, mp):
+        x = np.array(x, dtype=np.float64)
+        self.lib.orc_plant_rk4(_ptr(x), float(u), float(dt), len(x), _ptr(np.ascontiguousarray(mp, dtype=np.float64)))
+        return x
+
+    def ekf_jacobian(self, x, dt, mp):
+        F = np.zeros((10, 10))
+        self.lib.orc_ekf_jacobian(_ptr(np.ascontiguousarray(x, dtype=np.float64)), float(dt),
+                                  _ptr(np.ascontiguousarray(mp, dtype=np.float64)), _ptr(F))
+        return F
+
+    def ekf_time_update(self, x, P, u, dt, mp, Qd):
+        x = np.array(x, dtype=np.float64); P = np.array(P, dtype=np.float64)
+        self.lib.orc_ekf_time_update(_ptr(x), _ptr(P), float(u), float(dt),
+                                     _ptr(np.ascontiguousarray(mp, dtype=np.float64)),
+                                     _ptr(np.ascontiguousarray(Qd, dtype=np.float64)))
+        return x, P
+
+    def ekf_meas_update(self, x, P, y, Rd):
+        x = np.array(x, dtype=np.float64); P = np.array(P, dtype=np.float64)
+        self.lib.orc_ekf_meas_update(_ptr(x), _ptr(P), _ptr(np.ascontiguousarray(y, dtype=np.float64)),
+                                     _ptr(np.ascontiguousarray(Rd, dtype=np.float64)))
+        return x, P
+
+    # -- planners ---------------------------------------------------------
+    def skidpad_waypoints(self, x, y, heading, lap, prev_progress, v, N, dt):
+        wp = np.zeros((N + 1, 4)); sp = np.zeros(N + 1); pp = np.array([prev_progress], dtype=np.float64)
+        p0 = self.lib.orc_skidpad_waypoints(float(x), float(y), float(heading), int(lap), _ptr(pp), float(v), int(N),
+                                            float(dt), _ptr(wp), _ptr(sp))
+        return wp, sp, p0, float(pp[0])
+
+    def step_waypoints(self, x, y, heading, v, N, dt):
+        wp = np.zeros((N + 1, 4)); sp = np.zeros(N + 1); ab = np.zeros((N + 1, 4))
+        p0 = self.lib.orc_step_waypoints(float(x), float(y), float(heading), float(v), int(N), float(dt), _ptr(wp),
+                                         _ptr(sp), _ptr(ab))
+        return wp, sp, p0, ab
+
+    # -- controllers ------------------------------------------------------
+    def optimize(self, cfg, x0_7, wp, p, d_hat=0.0, lin_x=None, lin_u=None, tol=None):
+        N = int(cfg[1])
+        traj = np.zeros((N + 1, 7)); U = np.zeros(N); lam = np.zeros(2 * N); info = np.zeros(4)
+        tol = tol or self.tol
+        st = self.lib.orc_mpc_optimize(_ptr(cfg), _ptr(np.ascontiguousarray(x0_7, dtype=np.float64)),
+                                       _ptr(np.ascontiguousarray(wp, dtype=np.float64)),
+                                       _ptr(np.ascontiguousarray(p, dtype=np.float64)), float(d_hat), _ptr(lin_x),
+                                       _ptr(lin_u), _ptr(traj), _ptr(U), _ptr(lam), _ptr(info), tol[0], tol[1], tol[2])
+        return st, traj, U, lam, info
+
+    def skidpad_step(self, cfg, state8, lap, prev_progress, target_vel, lin_x=None, lin_u=None, tol=None):
+        tol = tol or self.tol
+        st8 = np.array(state8, dtype=np.float64); lp = C.c_int(int(lap)); pp = np.array([prev_progress], dtype=np.float64)
+        u0 = np.zeros(1); info = np.zeros(4)
+        st = self.lib.orc_skidpad_step(_ptr(cfg), _ptr(st8), C.byref(lp), _ptr(pp), float(target_vel), _ptr(lin_x),
+                                       _ptr(lin_u), _ptr(u0), _ptr(info), tol[0], tol[1], tol[2])
+        return st, st8, lp.value, float(pp[0]), float(u0[0]), info
+
+    def skidpad_run(self, cfg, states, laps, prev_progress, target_vel, nsteps, record=True, tol=None):
+        """states (B,8) / laps (B,) int32 / prev_progress (B,) are updated in place."""
+        tol = tol or self.tol
+        B = states.shape[0]
+        assert states.flags.c_contiguous and laps.dtype == np.int32
+        uh = np.zeros((nsteps, B)) if record else None
+        iters = self.lib.orc_skidpad_run(_ptr(cfg), _ptr(states), laps.ctypes.data_as(_ip), _ptr(prev_progress),
+                                         float(target_vel), B, int(nsteps), _ptr(uh), tol[0], tol[1], tol[2])
+        return uh, int(iters)
+
+
+# ---------------------------------------------------------------------------
+# controller configuration (host-side restatement of the reference constructors)
+# ---------------------------------------------------------------------------
+_DEFAULT_CFG_DIR = os.path.join(os.path.dirname(_HERE), "mpc_amd", "config")
+
+
+def load_params(kind: str, path: str | None = None) -> dict:
+    name = {"L": "parameters_L.yaml", "OFL": "parameters_L.yaml", "LPV": "parameters_LPV.yaml"}[kind]
+    with open(path or os.path.join(_DEFAULT_CFG_DIR, name)) as fh:
+        return yaml.safe_load(fh)
+
+
+def model_params(params: dict, orc: Oracle | None = None) -> np.ndarray:
+    m = params["model"]
+    lf = m["x_cg"] * m["wbase"]; lr = (1 - m["x_cg"]) * m["wbase"]
+    Cf, Cr = (orc or Oracle()).tyre_stiffness(m["m"], m["x_cg"])
+    return np.array([m["m"], m["I_z"], lf, lr, Cf, Cr], dtype=np.float64)
+
+
+def l_model_continuous(mp, vx, eps=1e-3):
+    """A_c(vx) of the linear model, LMPC2.py:127-149 (a12 divides the whole bracket)."""
+    m, Iz, lf, lr, Cf, Cr = mp
+    A = np.zeros((6, 6))
+    A[1, 2] = vx; A[1, 3] = 1.0; A[2, 4] = 1.0
+    A[3, 3] = -(Cf + Cr) / (m * vx + eps)
+    A[3, 4] = (-vx + (Cr * lr - Cf * lf)) / (m * vx + eps)
+    A[3, 5] = -Cf / m
+    A[4, 3] = (lr * Cr - lf * Cf) / (Iz * vx + eps)
+    A[4, 4] = -(lf * lf * Cf + lr * lr * Cr) / (Iz * vx + eps)
+    A[4, 5] = -lf * Cf / Iz
+    return A
+
+
+def dare_terminal(mp, dt, W):
+    """LMPC2.py:349-440: float32-cast forward-Euler (A,B) at vx=15 without px, Q'=diag(W11,W22,0,0,W33),
+    R'=W[4,4]; returns (P, K, A5, B5)."""
+    A = (np.eye(6) + dt * l_model_continuous(mp, 15.0)).astype(np.float32)[1:, 1:]
+    B = np.zeros((6, 1)); B[5, 0] = dt
+    B = B.astype(np.float32)[1:, :]
+    Q = np.diag([W[1, 1], W[2, 2], 0.0, 0.0, W[3, 3]])
+    R = np.array([[W[4, 4]]])
+    Ad, Bd = A.astype(np.float64), B.astype(np.float64)
+    P = scipy.linalg.solve_discrete_are(Ad, Bd, Q, R)
+    K = np.linalg.solve(Bd.T @ P @ Bd + R, Bd.T @ P @ Ad)
+    return P, K, A, B
+
+
+def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Oracle | None = None) -> np.ndarray:
+    params = params or load_params(kind)
+    mp = model_params(params, orc)
+    dt = Tf / N
+    c = params["controller"]
+    W = np.zeros((7, 7))
+    W[:6, :6] = np.array(c["Q"], dtype=np.float64) * c["q"]
+    W[6:, 6:] = np.array(c["R"], dtype=np.float64) * c["r"]
+    We = np.zeros((6, 6))
+    if kind == "LPV":
+        We[:, :] = W[:6, :6]                       # LPVMPC.py:217: W_e = W
+    else:
+        P, _, _, _ = dare_terminal(mp, dt, W)
+        beta = c["beta"] if kind == "L" else 1.0   # LMPC2.py:260 vs OFLMPC2.py:279
+        We[1:, 1:] = beta * 0.5 * P
+    cfg = np.zeros(CFG_LEN)
+    cfg[0] = KIND[kind]; cfg[1] = N; cfg[2] = dt; cfg[3:9] = mp
+    cfg[9] = params["model"]["max_steering_angle"]; cfg[10] = params["model"]["max_steering_rate"]
+    cfg[11:18] = np.diag(W); cfg[18:54] = We.reshape(-1); cfg[54] = 1e-3
+    return cfg
+
+
+# ---------------------------------------------------------------------------
+# dense KKT certificate of the condensed QP (numpy; independent of the C solver)
+# ---------------------------------------------------------------------------
+def condensed_qp(cfg, x0_7, wp, p, d_hat=0.0):
+    """Dense (H, g, A, lo, up) of the L/OFL problem built by explicit prediction matrices."""
+    kind, N, dt = int(cfg[0]), int(cfg[1]), cfg[2]
+    assert kind in (0, 1)
+    mp = cfg[3:9]
+    wq = dt * cfg[11:17]; wr = dt * cfg[17]; QN = cfg[18:54].reshape(6, 6)
+    xs = [np.array([0, 0, 0, x0_7[4], x0_7[5], x0_7[6]], dtype=np.float64)]
+    G = np.zeros((N + 1, 6, N))
+    b = np.zeros(6); b[5] = dt
+    for k in range(N):
+        A = np.eye(6) + dt * l_model_continuous(mp, p[k])
+        c = np.zeros(6); c[0] = dt * p[k]
+        if kind == 1:
+            c[3] = dt * d_hat
+        xs.append(A @ xs[-1] + c)
+        G[k + 1] = A @ G[k]
+        G[k + 1][:, k] = b
+    xr = np.zeros((N + 1, 6)); xr[:, 0] = wp[:, 0]; xr[:, 1] = wp[:, 1]; xr[:, 2] = wp[:, 3]
+    H = wr * np.eye(N); g = np.zeros(N)
+    for k in range(1, N):
+        H += G[k].T @ (wq[:, None] * G[k]); g += G[k].T @ (wq * (xs[k] - xr[k]))
+    H += G[N].T @ QN @ G[N]; g += G[N].T @ QN @ (xs[N] - xr[N])
+    T = np.tril(np.ones((N, N)))[: N - 1] * dt          # delta_{k+1} - delta_0, k = 0..N-2
+    A = np.vstack([np.eye(N), T])
+    lo = np.concatenate([-cfg[10] * np.ones(N), (-cfg[9] - x0_7[6]) * np.ones(N - 1)])
+    up = np.concatenate([cfg[10] * np.ones(N), (cfg[9] - x0_7[6]) * np.ones(N - 1)])
+    return H, g, A, lo, up
+
+
+def kkt_residuals(H, g, A, lo, up, U, lam):
+    """lam: signed multipliers (positive at the upper bound).  Returns (stationarity, primal, complementarity, sign)."""
+    v = A @ U
+    stat = np.abs(H @ U + g + A.T @ lam).max()
+    prim = max((v - up).max(), (lo - v).max(), 0.0)
+    comp = np.abs(np.where(lam > 0, lam * (up - v), lam * (v - lo))).max()
+    return stat, prim, comp
