@@ -1,0 +1,118 @@
+/*
+ * mpc_amd.h -- C ABI of libmpc_amd.so: the MI355X (gfx950) implementation of the skidpad MPC
+ * per-step control path (plan -> linearise/condense -> QP solve -> RK4 plant -> EKF).
+ *
+ * All buffers are caller-owned DEVICE pointers unless a parameter says "host".  Scenario records are
+ * contiguous ("scenario-major"): state[B][8], wp[B][N+1][4], U[B][N] ... so that the wavefront that
+ * owns a scenario reads its record with one coalesced access.  Every entry point is asynchronous on
+ * the hipStream_t passed as `void *stream` (NULL = default stream) and returns 0 on success or a
+ * negative MPC_E* code; mpc_last_error() gives the text.  No exceptions cross this boundary and the
+ * library owns nothing but the handle and its workspace.
+ *
+ * The reference has no FFI of its own for this path: its controllers hand the problem to
+ * acados_template's ctypes binding (AcadosOcpSolver.cost_set/set/solve_for_x0/get, LMPC2.py:301-329,
+ * LPVMPC.py:260-312, OFLMPC2.py:320-349).  The entry points below are what that binding is
+ * replaced by; each cites the reference interface it stands in for.
+ */
+#ifndef MPC_AMD_H
+#define MPC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_OK 0
+#define MPC_EINVAL (-1)   /* bad argument / unsupported horizon */
+#define MPC_EHIP (-2)     /* a HIP runtime call failed */
+#define MPC_ENOMEM (-3)
+
+#define MPC_KIND_L 0      /* LMPC2.py   LOcp   */
+#define MPC_KIND_OFL 1    /* OFLMPC2.py OFLOcp */
+#define MPC_KIND_LPV 2    /* LPVMPC.py  LPVOcp */
+
+#define MPC_PLANNER_SKIDPAD 0 /* utils/path_planning.py SkidpadPlanner */
+#define MPC_PLANNER_STEP 1    /* utils/step_planning.py StepPlanner    */
+
+#define MPC_MAX_HORIZON 64
+
+/* Controller definition; what the reference's constructors derive from parameters_*.yaml
+ * (LMPC2.py:14-96, LPVMPC.py:10-92, OFLMPC2.py:16-100). */
+typedef struct mpc_config {
+    int kind;            /* MPC_KIND_*                                                        */
+    int N;               /* horizon, 2..MPC_MAX_HORIZON                                       */
+    int B;               /* number of scenarios the workspace is sized for                    */
+    int device;          /* HIP device ordinal                                                */
+    double dt;           /* Tf / N                                                            */
+    double mp[6];        /* m, I_z, lf, lr, Cf, Cr                                            */
+    double max_steering; /* |delta| bound, stages 1..N-1                                      */
+    double max_rate;     /* |u| bound, stages 0..N-1                                          */
+    double w[7];         /* diag of W = blkdiag(Q*q, R*r); stage cost is dt * 1/2 |y-yref|^2_W */
+    double We[36];       /* terminal weight on the 6 states (row-major)                       */
+    double eps;          /* tyre-model denominator offset (1e-3)                              */
+    double tol_mu;       /* interior-point stop: complementarity                              */
+    double tol_res;      /* interior-point stop: stationarity / feasibility residual           */
+    int max_iter;        /* interior-point iteration cap                                      */
+    int lpv_lin_prev;    /* LPV only: 0 = lin_mode "reference", 1 = "prev_iter" (LPVMPC.py:254) */
+} mpc_config;
+
+typedef struct mpc_handle mpc_handle;
+
+/* Replaces AcadosOcpSolver(ocp) construction (LMPC2.py:94). */
+int mpc_create(const mpc_config *cfg, mpc_handle **out);
+void mpc_destroy(mpc_handle *h);
+const char *mpc_last_error(const mpc_handle *h); /* h may be NULL: last error of mpc_create */
+
+/* Optional per-scenario model parameters mp[B][6] (tyre / mass sweeps); NULL restores cfg.mp. */
+int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario);
+
+/* optimize(): the yref/p set loop + solve_for_x0 + x/u get loop of LMPC2.py:296-347,
+ * OFLMPC2.py:315-367, LPVMPC.py:254-341, for B scenarios.
+ *   x0      [B][7]  reduced state [pose(4), vy, r, delta]
+ *   wp      [B][N+1][4] car-frame waypoints, p [B][N+1] speeds, d_hat [B] (OFL) or NULL
+ *   lin_x   [B][6][N+1], lin_u [B][N]  LPV prev_x / prev_u, read and updated (NULL otherwise)
+ *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B] (0 ok, 2 iteration cap), iters_out [B] */
+int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const double *wp, const double *p,
+                   const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out,
+                   int *status_out, int *iters_out);
+
+/* One fused closed-loop step per scenario: plan -> optimize -> RK4 plant -> lap count
+ * (SkidpadSimulator.step, skidpad_simulator.py:109-135; StepSimulator.simulate body, simulator.py:178-202).
+ *   state [B][8] plant state (updated), lap [B] (updated), prev_progress [B] planner memory (updated),
+ *   target_vel [B]; u0_out [B]; wp_out [B][N+1][4] / traj_out [B][N+1][7] / U_out [B][N] optional (NULL). */
+int mpc_closed_loop_step(mpc_handle *h, void *stream, int B, int planner, double *state, int *lap,
+                         double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
+                         double *u0_out, double *wp_out, double *traj_out, double *U_out, int *status_out,
+                         int *iters_out);
+
+/* Dynamics.single_track_model / rk4_integraton (continuous_dynamics.py:90-133): x [B][nx], nx = 8 or 10. */
+int mpc_plant_rk4(void *stream, int B, int nx, double dt, const double *mp6_host, double *x, const double *u);
+int mpc_plant_f(void *stream, int B, int nx, const double *mp6_host, const double *x, const double *u, double *xdot);
+
+/* CarEKF (EKF.py:38-49,65-74) with Dynamics.jacobian_forward_euler (continuous_dynamics.py:167-210):
+ * x [B][10], P [B][10][10]; q_diag / r_diag are host arrays of 10 / 7. */
+int mpc_ekf_time_update(void *stream, int B, double dt, const double *mp6_host, const double *q_diag_host, double *x,
+                        double *P, const double *u);
+int mpc_ekf_measurement_update(void *stream, int B, const double *r_diag_host, double *x, double *P, const double *y,
+                               double *K_out /* [B][10][7] or NULL */);
+/* CarEKF.kalman_gain (EKF.py:65-74) on its own: K_out [B][10][7] from P [B][10][10]. */
+int mpc_ekf_kalman_gain(void *stream, int B, const double *r_diag_host, const double *P, double *K_out);
+int mpc_ekf_jacobian(void *stream, int B, double dt, const double *mp6_host, const double *x, double *F);
+
+/* SkidpadPlanner.request_waypoints (utils/path_planning.py:220-261, laps 0..7) and
+ * StepPlanner.request_waypoints (utils/step_planning.py:88-117): pose [B][3] = x, y, heading;
+ * wp_out [B][N+1][4]; progress_out [B]; abs_out [B][N+1][4] (step planner, may be NULL). */
+int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
+                     const double *target_vel, double *wp_out, double *progress_out);
+int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, const double *target_vel, double *wp_out,
+                  double *progress_out, double *abs_out);
+
+/* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
+ * copied to a host array of 16 doubles after synchronising the stream:
+ *   [0] scenarios, [1] sum iterations, [2] count status != 0, [3] count constrained solves,
+ *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual; rest reserved. */
+int mpc_get_stats(mpc_handle *h, void *stream, double *host16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_AMD_H */

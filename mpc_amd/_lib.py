@@ -1,0 +1,82 @@
+"""ctypes binding of libmpc_amd.so (include/mpc_amd.h).  There is no CPU fallback: a missing library or
+a failing call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+KIND = {"L": 0, "OFL": 1, "LPV": 2}
+PLANNER_SKIDPAD, PLANNER_STEP = 0, 1
+MAX_HORIZON = 64
+
+
+class MpcConfig(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("N", C.c_int), ("B", C.c_int), ("device", C.c_int),
+        ("dt", C.c_double), ("mp", C.c_double * 6), ("max_steering", C.c_double), ("max_rate", C.c_double),
+        ("w", C.c_double * 7), ("We", C.c_double * 36), ("eps", C.c_double), ("tol_mu", C.c_double),
+        ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
+    ]
+
+
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_SIGS = {
+    "mpc_create": ([C.POINTER(MpcConfig), C.POINTER(_vp)], C.c_int),
+    "mpc_destroy": ([_vp], None),
+    "mpc_last_error": ([_vp], C.c_char_p),
+    "mpc_set_model_params": ([_vp, _vp], C.c_int),
+    "mpc_solve_only": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
+    "mpc_closed_loop_step": ([_vp, _vp, C.c_int, C.c_int] + [_vp] * 12, C.c_int),
+    "mpc_plant_rk4": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _vp, _vp], C.c_int),
+    "mpc_plant_f": ([_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp], C.c_int),
+    "mpc_ekf_time_update": ([_vp, C.c_int, C.c_double, _dp, _dp, _vp, _vp, _vp], C.c_int),
+    "mpc_ekf_measurement_update": ([_vp, C.c_int, _dp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_ekf_kalman_gain": ([_vp, C.c_int, _dp, _vp, _vp], C.c_int),
+    "mpc_ekf_jacobian": ([_vp, C.c_int, C.c_double, _dp, _vp, _vp], C.c_int),
+    "mpc_plan_skidpad": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Loads the shared library (building it with hipcc first if it is absent and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (needs hipcc)")
+        _build.build_library()
+    lib = C.CDLL(path)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = the build is out of date
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def hptr(a: np.ndarray):
+    """Host double pointer of a C-contiguous float64 array."""
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_dp)
+
+
+def check(rc: int, handle=None, what: str = "libmpc_amd") -> None:
+    if rc != 0:
+        msg = load().mpc_last_error(handle).decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,81 @@
+"""Batched closed-loop simulators: B independent scenarios advanced by one fused kernel launch per step
+(plan -> linearise/condense -> QP -> RK4 plant -> lap count), state resident in HBM.
+
+Per scenario the semantics are those of SkidpadSimulator.step (skidpad_simulator.py:109-135) and of the
+loop body of StepSimulator.simulate (simulator.py:178-202)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _dev, _lib
+from .controllers import LOcp, LPVOcp
+
+
+class _ClosedLoopBatch:
+    planner = _lib.PLANNER_SKIDPAD
+
+    def __init__(self, N, Tf, starting_states, starting_laps=None, model="L", device=None, target_vel=None, **ctl_kw):
+        states = np.ascontiguousarray(starting_states, dtype=np.float64)
+        if states.ndim != 2 or states.shape[1] != 8:
+            raise ValueError("starting_states must be (B, 8): [x, y, cos, sin, vx, vy, r, delta]")
+        self.B = B = states.shape[0]
+        self.N, self.Tf, self.dt = int(N), float(Tf), float(Tf) / int(N)
+        if model == "L":
+            self.ocp = LOcp(N, Tf, batch=B, device=device, **ctl_kw)
+        elif model == "LPV":
+            self.ocp = LPVOcp(N, Tf, batch=B, device=device, **ctl_kw)
+        else:
+            raise ValueError("model must be 'L' or 'LPV' for the fused closed loop")
+        self.MPC_controller = self.ocp
+        dev = self.device = self.ocp.device
+        self.state = _dev.f64(states, dev)
+        self.lap = _dev.i32(np.zeros(B) if starting_laps is None else starting_laps, dev)
+        self.prev_progress = torch.zeros(B, dtype=torch.float64, device=dev)
+        tv = states[:, 4] if target_vel is None else np.broadcast_to(np.asarray(target_vel, dtype=np.float64), (B,))
+        self.target_vel = _dev.f64(tv, dev)               # SkidpadPlanner(target_vel=starting_velocity[0])
+        self.u0 = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        if model == "LPV":
+            self.lin_x = torch.zeros((B, 6, self.N + 1), dtype=torch.float64, device=dev)
+            self.lin_u = torch.zeros((B, self.N), dtype=torch.float64, device=dev)
+        else:
+            self.lin_x = self.lin_u = None
+        self.planned_references = None
+        self.planned_trajectory = None
+        self.planned_inputs = None
+
+    def step(self, record_plan: bool = False) -> torch.Tensor:
+        """One closed-loop step for every scenario; returns the applied inputs (B,) (device tensor, no sync)."""
+        dev = self.device
+        if record_plan and self.planned_references is None:
+            self.planned_references = torch.zeros((self.B, self.N + 1, 4), dtype=torch.float64, device=dev)
+            self.planned_trajectory = torch.zeros((self.B, self.N + 1, 7), dtype=torch.float64, device=dev)
+            self.planned_inputs = torch.zeros((self.B, self.N), dtype=torch.float64, device=dev)
+        s = self.ocp.solver
+        rc = s._lib.mpc_closed_loop_step(
+            s.h, _dev.stream_ptr(dev), self.B, self.planner, _dev.ptr(self.state), _dev.ptr(self.lap),
+            _dev.ptr(self.prev_progress), _dev.ptr(self.target_vel), _dev.ptr(self.lin_x), _dev.ptr(self.lin_u),
+            _dev.ptr(self.u0), _dev.ptr(self.planned_references if record_plan else None),
+            _dev.ptr(self.planned_trajectory if record_plan else None),
+            _dev.ptr(self.planned_inputs if record_plan else None), _dev.ptr(self.status), _dev.ptr(self.iters))
+        _lib.check(rc, s.h, "mpc_closed_loop_step")
+        return self.u0
+
+    def simulate(self, n_steps: int):
+        """n closed-loop steps; returns (states (n,B,8), inputs (n,B)) as device tensors."""
+        xs = torch.empty((n_steps, self.B, 8), dtype=torch.float64, device=self.device)
+        us = torch.empty((n_steps, self.B), dtype=torch.float64, device=self.device)
+        for i in range(n_steps):
+            us[i] = self.step()
+            xs[i] = self.state
+        return xs, us
+
+
+class SkidpadBatch(_ClosedLoopBatch):
+    planner = _lib.PLANNER_SKIDPAD
+
+
+class StepBatch(_ClosedLoopBatch):
+    planner = _lib.PLANNER_STEP

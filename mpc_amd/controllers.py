@@ -1,0 +1,305 @@
+"""Host side of the MPC controllers: the reference's controller classes (LOcp, OFLOcp, LPVOcp) with the
+acados solver object replaced by a handle of libmpc_amd.so.
+
+Set-up (yaml, tyre stiffness, cost matrices, DARE terminal weight) is host arithmetic done once, as in the
+reference's constructors (LMPC2.py:14-96,349-440; OFLMPC2.py:16-100; LPVMPC.py:10-92).  Every optimize()
+runs on the GPU through the C ABI; there is no CPU solve path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+import time
+
+import numpy as np
+import scipy.linalg
+import torch
+import yaml
+
+from . import _dev, _lib
+
+log = logging.getLogger("mpc_amd")
+_CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
+
+# cornering stiffness over vertical load (LMPC2.py:98-112)
+_C_DATA_Y = np.array([1.537405752168591e04, 2.417765976460659e04, 3.121158998819641e04, 3.636055041362088e04])
+_C_DATA_X = [300, 500, 700, 900]
+
+
+def tyre_stiffness(m: float, x_cg: float) -> tuple[float, float]:
+    Cf = np.interp((9.81 * m / 2) * (1 - x_cg), _C_DATA_X, _C_DATA_Y)
+    Cr = np.interp((9.81 * m / 2) * x_cg, _C_DATA_X, _C_DATA_Y)
+    return float(Cf), float(Cr)
+
+
+def read_parameters(filename: str, params=None) -> dict:
+    """The reference opens parameters_*.yaml relative to the working directory (LMPC2.py:31); the same file is
+    looked up there first, then the copy shipped in mpc_amd/config.  `params` may be a dict or a path."""
+    if isinstance(params, dict):
+        return params
+    path = params if isinstance(params, str) else (filename if os.path.exists(filename) else os.path.join(_CONFIG_DIR, filename))
+    with open(path, "r") as fh:
+        return yaml.safe_load(fh)
+
+
+class SolverHandle:
+    """Owns one mpc_handle; stands where the reference keeps its AcadosOcpSolver (`ocp.solver`)."""
+
+    def __init__(self, cfg: _lib.MpcConfig):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.mpc_create(C.byref(cfg), C.byref(h))
+        _lib.check(rc, None, "mpc_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.mpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _CondensedMpc:
+    """Shared machinery of the three quadratic controllers."""
+
+    kind = "L"
+    param_file = "parameters_L.yaml"
+    n_states = 6
+    n_inputs = 1
+    n_outputs = 5
+
+    def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
+                 batch: int = 1, tol_mu: float = 1e-13, tol_res: float = 1e-12, max_iter: int = 60):
+        if not discrete:
+            raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
+        log.setLevel(logging.DEBUG if debug else logging.INFO)
+        self.params = read_parameters(self.param_file, params)
+        self.discrete = discrete
+        self.N = int(N)
+        self.Tf = float(Tf)
+        self.dt = self.Tf / self.N
+        m = self.params["model"]
+        self.m, self.I_z, self.wbase, self.x_cg = m["m"], m["I_z"], m["wbase"], m["x_cg"]
+        self.lf = self.x_cg * self.wbase
+        self.lr = (1 - self.x_cg) * self.wbase
+        self.Cf, self.Cr = self.get_tyre_stiffness()
+        self.max_steering = m["max_steering_angle"]
+        self.max_steering_rate = m["max_steering_rate"]
+        self.x_lin_point = np.zeros(6)
+        self.u_lin_point = np.zeros(1)
+        self.p_lin_point = np.array([15.0])
+        self.W, self.W_e = self._cost_matrices()
+        self.device = _dev.require_gpu(device)
+        self.batch = int(batch)
+        self._tol = (tol_mu, tol_res, max_iter)
+        self.solver = SolverHandle(self._make_config())
+        self.metrics = {"runtime": []}
+        self._bufs = {}
+
+    # ---- set-up -----------------------------------------------------------------------------
+    def get_tyre_stiffness(self) -> tuple[float, float]:
+        return tyre_stiffness(self.m, self.x_cg)
+
+    def model_params(self) -> np.ndarray:
+        return np.array([self.m, self.I_z, self.lf, self.lr, self.Cf, self.Cr], dtype=np.float64)
+
+    def continuous_A(self, vx: float) -> np.ndarray:
+        """Jacobian of the linear model at speed vx (LMPC2.py:127-157)."""
+        A = np.zeros((6, 6))
+        A[1, 2] = vx; A[1, 3] = 1.0; A[2, 4] = 1.0
+        A[3, 3] = -(self.Cf + self.Cr) / (self.m * vx + 0.001)
+        A[3, 4] = (-vx + (self.Cr * self.lr - self.Cf * self.lf)) / (self.m * vx + 0.001)
+        A[3, 5] = -self.Cf / self.m
+        A[4, 3] = (self.lr * self.Cr - self.lf * self.Cf) / (self.I_z * vx + 0.001)
+        A[4, 4] = -(self.lf * self.lf * self.Cf + self.lr * self.lr * self.Cr) / (self.I_z * vx + 0.001)
+        A[4, 5] = -self.lf * self.Cf / self.I_z
+        return A
+
+    def _stage_weights(self) -> np.ndarray:
+        c = self.params["controller"]
+        Q = np.array(c["Q"], dtype=np.float64) * c["q"]
+        R = np.array(c["R"], dtype=np.float64) * c["r"]
+        if np.any(Q - np.diag(np.diag(Q))):
+            raise NotImplementedError("off-diagonal state weights are not supported by the condensing kernel")
+        W = np.zeros((7, 7))
+        W[:6, :6] = Q
+        W[6:, 6:] = R
+        return W
+
+    def _cost_matrices(self):
+        W = self._stage_weights()
+        return W, W.copy()
+
+    def _make_config(self) -> _lib.MpcConfig:
+        cfg = _lib.MpcConfig()
+        cfg.kind = _lib.KIND[self.kind]
+        cfg.N = self.N
+        cfg.B = self.batch
+        cfg.device = self.device.index
+        cfg.dt = self.dt
+        cfg.mp[:] = list(self.model_params())
+        cfg.max_steering = self.max_steering
+        cfg.max_rate = self.max_steering_rate
+        cfg.w[:] = list(np.diag(self.W))
+        cfg.We[:] = list(np.asarray(self.W_e)[:6, :6].reshape(-1))
+        cfg.eps = 0.001
+        cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
+        cfg.lpv_lin_prev = 0
+        return cfg
+
+    def stability(self):
+        """DARE terminal weight exactly as LMPC2.py:349-440 poses it: forward-Euler (A,B) at vx=15 cast to
+        float32, px dropped, Q' = diag(W11, W22, 0, 0, W33), R' = W[4,4].  The control-admissible set the
+        reference also estimates there (stability.py) never enters the OCP and is not computed."""
+        A = (np.eye(6) + self.dt * self.continuous_A(float(self.p_lin_point[0]))).astype(np.float32)
+        B = np.zeros((6, 1)); B[5, 0] = self.dt
+        B = B.astype(np.float32)
+        A = A[1:, 1:]; B = B[1:, :]
+        self.A_stability, self.B_stability = A, B
+        W = self.W
+        Q = np.diag([W[1, 1], W[2, 2], 0.0, 0.0, W[3, 3]])
+        R = np.array([[W[4, 4]]])
+        Ad, Bd = A.astype(np.float64), B.astype(np.float64)
+        self.P = scipy.linalg.solve_discrete_are(Ad, Bd, Q, R)
+        self.K = np.linalg.solve(Bd.T @ self.P @ Bd + R, Bd.T @ self.P @ Ad)
+        self.C = None
+
+    # ---- per step -----------------------------------------------------------------------------
+    def waypoints_to_references(self, waypoints: np.ndarray) -> np.ndarray:
+        references = np.zeros([self.N + 1, self.n_states + self.n_inputs])
+        references[:, 0] = waypoints[:, 0]; references[:, 1] = waypoints[:, 1]; references[:, 2] = waypoints[:, 3]
+        return references
+
+    def _buf(self, name, shape, dtype=torch.float64):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def solve_batched(self, x0, waypoints, p, d_hat=None, lin_x=None, lin_u=None, want_trajectory=True):
+        """Batched optimize(): device tensors in, device tensors out, no host synchronisation.
+        x0 (B,7), waypoints (B,N+1,4), p (B,N+1) [, d_hat (B,)]."""
+        dev = self.device
+        x0 = _dev.f64(x0, dev); waypoints = _dev.f64(waypoints, dev); p = _dev.f64(p, dev)
+        B = x0.shape[0]
+        if B > self.batch:
+            raise ValueError(f"batch {B} exceeds the workspace of this controller ({self.batch})")
+        assert x0.shape == (B, 7) and waypoints.shape == (B, self.N + 1, 4) and p.shape == (B, self.N + 1)
+        U = torch.empty((B, self.N), dtype=torch.float64, device=dev)
+        traj = torch.empty((B, self.N + 1, 7), dtype=torch.float64, device=dev) if want_trajectory else None
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        dh = _dev.f64(d_hat, dev) if d_hat is not None else None
+        rc = self.solver._lib.mpc_solve_only(self.solver.h, _dev.stream_ptr(dev), B, _dev.ptr(x0), _dev.ptr(waypoints),
+                                             _dev.ptr(p), _dev.ptr(dh), _dev.ptr(lin_x), _dev.ptr(lin_u), _dev.ptr(U),
+                                             _dev.ptr(traj), _dev.ptr(status), _dev.ptr(iters))
+        _lib.check(rc, self.solver.h, "mpc_solve_only")
+        return U, traj, status, iters
+
+    def _optimize_one(self, x0, waypoints, p, d_hat=None, lin_x=None, lin_u=None):
+        t0 = time.perf_counter()
+        x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+        wp = np.asarray(waypoints, dtype=np.float64)
+        pv = np.asarray(p, dtype=np.float64).reshape(-1)
+        if x0.shape[0] < 7 or wp.shape != (self.N + 1, 4) or pv.shape[0] < self.N:
+            raise ValueError("optimize: x0 needs 7 entries, waypoints (N+1,4), p at least N speeds")
+        pfull = np.empty(self.N + 1); pfull[: min(len(pv), self.N + 1)] = pv[: self.N + 1]
+        if len(pv) < self.N + 1:
+            pfull[self.N] = pv[self.N - 1]          # the stage-N parameter is never used (LMPC2.py:301-303)
+        dh = None if d_hat is None else np.array([float(d_hat)])
+        U, traj, status, iters = self.solve_batched(x0[None, :7], wp[None], pfull[None], dh, lin_x, lin_u)
+        U = U.cpu().numpy()[0]; traj = traj.cpu().numpy()[0]
+        st = int(status.item())
+        self.last_iterations = int(iters.item())
+        self.metrics["runtime"].append(time.perf_counter() - t0)
+        if st == 2:
+            log.warning("interior-point iteration cap reached (status 2)")
+        elif st != 0:
+            raise RuntimeError(f"MPC solve failed with status {st}")
+        return 0, traj, U.reshape(self.N, 1)
+
+    def stats(self) -> dict:
+        out = np.zeros(16)
+        rc = self.solver._lib.mpc_get_stats(self.solver.h, _dev.stream_ptr(self.device), _lib.hptr(out))
+        _lib.check(rc, self.solver.h, "mpc_get_stats")
+        keys = ["scenarios", "sum_iterations", "n_status_nonzero", "n_constrained", "sum_abs_u0", "max_abs_u0",
+                "max_complementarity", "max_residual"]
+        return dict(zip(keys, out[:8]))
+
+
+class LOcp(_CondensedMpc):
+    """Linear MPC, speed-parameterised 6-state model (LMPC2.py:12)."""
+
+    kind = "L"
+    param_file = "parameters_L.yaml"
+
+    def _cost_matrices(self):
+        W = self._stage_weights()
+        self.W = W
+        self.stability()
+        W_e = np.zeros((7, 7))
+        W_e[1:-1, 1:-1] = self.params["controller"]["beta"] * 1 / 2 * self.P       # LMPC2.py:255-260
+        return W, W_e
+
+    def optimize(self, x0, waypoints, p):
+        return self._optimize_one(x0, waypoints, p)
+
+
+class OFLOcp(_CondensedMpc):
+    """Offset-free linear MPC: the L model plus a side-force disturbance parameter (OFLMPC2.py:14)."""
+
+    kind = "OFL"
+    param_file = "parameters_L.yaml"
+    n_parameters = 1
+    n_disturbances = 1
+
+    def _cost_matrices(self):
+        W = self._stage_weights()
+        self.W = W
+        self.stability()
+        W_e = np.zeros((7, 7))
+        W_e[1:-1, 1:-1] = 1 / 2 * self.P                                            # OFLMPC2.py:274-279
+        self.B_d = np.zeros((6, 1)); self.B_d[3, 0] = 1 / self.m
+        self.C_d = np.eye(self.n_outputs, self.n_disturbances)
+        return W, W_e
+
+    def optimize(self, x0, waypoints, p, d_hat):
+        return self._optimize_one(x0, waypoints, p, d_hat=d_hat)
+
+
+class LPVOcp(_CondensedMpc):
+    """LPV MPC: the nonlinear kinematic model re-linearised per stage and per step (LPVMPC.py:9)."""
+
+    kind = "LPV"
+    param_file = "parameters_LPV.yaml"
+    n_params = 1
+
+    def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, **kw):
+        super().__init__(N, Tf, discrete, debug, **kw)
+        self.prev_x = np.zeros((6, self.N + 1))
+        self.prev_u = np.zeros((1, self.N + 1))
+        self.metrics = {"runtime": [], "cost": [], "status": []}
+        self._lin_mode = "reference"
+
+    def optimize(self, x0, waypoints, p, lin_mode: str = "reference"):
+        if lin_mode not in ("reference", "prev_iter"):
+            raise ValueError(f"unknown lin_mode {lin_mode!r}")
+        if lin_mode != self._lin_mode:
+            # the linearisation rule is part of the solver definition: rebuild the handle
+            self._lin_mode = lin_mode
+            cfg = self._make_config(); cfg.lpv_lin_prev = 1 if lin_mode == "prev_iter" else 0
+            self.solver.close(); self.solver = SolverHandle(cfg)
+        lin_x = _dev.f64(self.prev_x[None], self.device)
+        lin_u = _dev.f64(np.asarray(self.prev_u)[:, : self.N][None, 0], self.device)
+        out = self._optimize_one(x0, waypoints, p, lin_x=lin_x, lin_u=lin_u)
+        self.prev_x = lin_x.cpu().numpy()[0]
+        self.prev_u = lin_u.cpu().numpy()
+        return out

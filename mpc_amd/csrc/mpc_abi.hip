@@ -1,0 +1,222 @@
+// extern "C" boundary of libmpc_amd.so (declared in include/mpc_amd.h).
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mpc_kernels.h"
+
+struct mpc_handle {
+    mpc_config cfg;
+    mpc::DevCfg dev;
+    double *Hws = nullptr;       // B * N * N condensed Hessians
+    double *stat = nullptr;      // B * 4 solver records
+    int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
+    double *mp_scen = nullptr;   // optional B * 6
+    double *stats16 = nullptr;   // device result of the statistics reduction
+    const int *last_iters = nullptr, *last_status = nullptr;
+    int last_B = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(mpc_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+static int hip_fail(mpc_handle *h, hipError_t e, const char *what)
+{
+    return fail(h, MPC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(h, call)                                        \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(h, e_, #call);    \
+    } while (0)
+
+extern "C" {
+
+const char *mpc_last_error(const mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mpc_create(const mpc_config *cfg, mpc_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, MPC_EINVAL, "mpc_create: null argument");
+    *out = nullptr;
+    if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_LPV) return fail(nullptr, MPC_EINVAL, "mpc_create: unknown kind");
+    if (!mpc::horizon_supported(cfg->N)) {
+        char b[160];
+        snprintf(b, sizeof b, "mpc_create: horizon N=%d has no compiled solver in this build", cfg->N);
+        return fail(nullptr, MPC_EINVAL, b);
+    }
+    if (cfg->B < 1 || !(cfg->dt > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: need B >= 1 and dt > 0");
+    if (!(cfg->w[6] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight R*r must be positive (strict convexity)");
+    mpc_handle *h = new (std::nothrow) mpc_handle();
+    if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
+    h->cfg = *cfg;
+    mpc::DevCfg &d = h->dev;
+    d.kind = cfg->kind; d.N = cfg->N; d.lpv_lin_prev = cfg->lpv_lin_prev; d.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 60;
+    d.dt = cfg->dt; d.eps = cfg->eps; d.max_steering = cfg->max_steering; d.max_rate = cfg->max_rate;
+    d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-13; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
+    memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);
+    hipError_t e = hipSetDevice(cfg->device);
+    const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
+    if (e == hipSuccess) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
+    if (e != hipSuccess) {
+        int rc = hip_fail(nullptr, e, "mpc_create: workspace allocation");
+        mpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return MPC_OK;
+}
+
+void mpc_destroy(mpc_handle *h)
+{
+    if (!h) return;
+    (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
+    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen);
+    delete h;
+}
+
+int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
+{
+    if (!h) return MPC_EINVAL;
+    if (!mp_per_scenario) { (void)hipFree(h->mp_scen); h->mp_scen = nullptr; return MPC_OK; }
+    const size_t bytes = (size_t)h->cfg.B * 6 * sizeof(double);
+    if (!h->mp_scen) HIP_TRY(h, hipMalloc(&h->mp_scen, bytes));
+    HIP_TRY(h, hipMemcpy(h->mp_scen, mp_per_scenario, bytes, hipMemcpyDeviceToDevice));
+    return MPC_OK;
+}
+
+static int check_batch(mpc_handle *h, int B, const char *who)
+{
+    if (!h) return MPC_EINVAL;
+    if (B < 1 || B > h->cfg.B) return fail(h, MPC_EINVAL, std::string(who) + ": B outside 1..cfg.B");
+    return MPC_OK;
+}
+
+int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const double *wp, const double *p,
+                   const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out,
+                   int *status_out, int *iters_out)
+{
+    if (int rc = check_batch(h, B, "mpc_solve_only")) return rc;
+    if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_solve_only: x0, wp, p and U_out are required");
+    if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_solve_only: LPV needs lin_x and lin_u");
+    mpc::SolveArgs a = {};
+    a.mode = mpc::MODE_SOLVE; a.B = B; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
+    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.U_out = U_out; a.traj_out = traj_out;
+    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.stat_out = h->stat;
+    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
+    return MPC_OK;
+}
+
+int mpc_closed_loop_step(mpc_handle *h, void *stream, int B, int planner, double *state, int *lap,
+                         double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
+                         double *u0_out, double *wp_out, double *traj_out, double *U_out, int *status_out,
+                         int *iters_out)
+{
+    if (int rc = check_batch(h, B, "mpc_closed_loop_step")) return rc;
+    if (planner != MPC_PLANNER_SKIDPAD && planner != MPC_PLANNER_STEP) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: unknown planner");
+    if (!state || !target_vel || !u0_out) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: state, target_vel and u0_out are required");
+    if (planner == MPC_PLANNER_SKIDPAD && (!lap || !prev_progress)) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: skidpad planner needs lap and prev_progress");
+    if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: LPV needs lin_x and lin_u");
+    if (h->cfg.kind == MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: the OFL loop runs on the estimate; use mpc_solve_only with the EKF entry points");
+    mpc::SolveArgs a = {};
+    a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
+    a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
+    a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws;
+    a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
+    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.stat_out = h->stat;
+    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
+    return MPC_OK;
+}
+
+int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
+{
+    if (!h || !host16) return MPC_EINVAL;
+    if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->last_iters, h->last_status, h->stats16));
+    HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    return MPC_OK;
+}
+
+#define AUX_TRY(call)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) return hip_fail(nullptr, e_, #call);            \
+    } while (0)
+
+int mpc_plant_rk4(void *stream, int B, int nx, double dt, const double *mp6_host, double *x, const double *u)
+{
+    if (B < 1 || (nx != 8 && nx != 10) || !mp6_host || !x || !u) return fail(nullptr, MPC_EINVAL, "mpc_plant_rk4: bad argument");
+    AUX_TRY(mpc::launch_plant_rk4((hipStream_t)stream, B, nx, dt, mp6_host, x, u));
+    return MPC_OK;
+}
+
+int mpc_plant_f(void *stream, int B, int nx, const double *mp6_host, const double *x, const double *u, double *xdot)
+{
+    if (B < 1 || (nx != 8 && nx != 10) || !mp6_host || !x || !u || !xdot) return fail(nullptr, MPC_EINVAL, "mpc_plant_f: bad argument");
+    AUX_TRY(mpc::launch_plant_f((hipStream_t)stream, B, nx, mp6_host, x, u, xdot));
+    return MPC_OK;
+}
+
+int mpc_ekf_time_update(void *stream, int B, double dt, const double *mp6_host, const double *q_diag_host, double *x,
+                        double *P, const double *u)
+{
+    if (B < 1 || !mp6_host || !q_diag_host || !x || !P || !u) return fail(nullptr, MPC_EINVAL, "mpc_ekf_time_update: bad argument");
+    AUX_TRY(mpc::launch_ekf_time_update((hipStream_t)stream, B, dt, mp6_host, q_diag_host, x, P, u));
+    return MPC_OK;
+}
+
+int mpc_ekf_measurement_update(void *stream, int B, const double *r_diag_host, double *x, double *P, const double *y,
+                               double *K_out)
+{
+    if (B < 1 || !r_diag_host || !x || !P || !y) return fail(nullptr, MPC_EINVAL, "mpc_ekf_measurement_update: bad argument");
+    AUX_TRY(mpc::launch_ekf_meas_update((hipStream_t)stream, B, r_diag_host, x, P, y, K_out, 0));
+    return MPC_OK;
+}
+
+int mpc_ekf_kalman_gain(void *stream, int B, const double *r_diag_host, const double *P, double *K_out)
+{
+    if (B < 1 || !r_diag_host || !P || !K_out) return fail(nullptr, MPC_EINVAL, "mpc_ekf_kalman_gain: bad argument");
+    AUX_TRY(mpc::launch_ekf_meas_update((hipStream_t)stream, B, r_diag_host, nullptr, const_cast<double *>(P), nullptr, K_out, 1));
+    return MPC_OK;
+}
+
+int mpc_ekf_jacobian(void *stream, int B, double dt, const double *mp6_host, const double *x, double *F)
+{
+    if (B < 1 || !mp6_host || !x || !F) return fail(nullptr, MPC_EINVAL, "mpc_ekf_jacobian: bad argument");
+    AUX_TRY(mpc::launch_ekf_jacobian((hipStream_t)stream, B, dt, mp6_host, x, F));
+    return MPC_OK;
+}
+
+int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
+                     const double *target_vel, double *wp_out, double *progress_out)
+{
+    if (B < 1 || N < 1 || !pose || !lap || !prev_progress || !target_vel || !wp_out) return fail(nullptr, MPC_EINVAL, "mpc_plan_skidpad: bad argument");
+    AUX_TRY(mpc::launch_plan_skidpad((hipStream_t)stream, B, N, dt, pose, lap, prev_progress, target_vel, wp_out, progress_out));
+    return MPC_OK;
+}
+
+int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, const double *target_vel, double *wp_out,
+                  double *progress_out, double *abs_out)
+{
+    if (B < 1 || N < 1 || !pose || !target_vel || !wp_out) return fail(nullptr, MPC_EINVAL, "mpc_plan_step: bad argument");
+    AUX_TRY(mpc::launch_plan_step((hipStream_t)stream, B, N, dt, pose, target_vel, wp_out, progress_out, abs_out));
+    return MPC_OK;
+}
+
+}  // extern "C"

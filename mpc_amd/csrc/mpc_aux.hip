@@ -1,0 +1,305 @@
+// Thread-per-scenario kernels for the pieces of the path that are called on their own through the
+// reference's class surface: plant (continuous_dynamics.py), EKF (EKF.py), planners (utils/*.py),
+// and the statistics reduction.  gfx950 only.
+#include "mpc_device.hpp"
+#include "mpc_kernels.h"
+
+namespace mpc {
+
+struct MP6 { double v[6]; };
+struct V10 { double v[10]; };
+struct V7 { double v[7]; };
+
+static inline MP6 mp6_from_host(const double *p) { MP6 m; for (int i = 0; i < 6; i++) m.v[i] = p[i]; return m; }
+__device__ __forceinline__ ModelParams to_mp(const MP6 &m) { return {m.v[0], m.v[1], m.v[2], m.v[3], m.v[4], m.v[5]}; }
+
+// ------------------------------------------------------------------------------------------ plant
+template <int NX>
+__global__ __launch_bounds__(256) void k_plant_rk4(int B, double dt, MP6 m, double *x, const double *u)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    double xs[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) xs[i] = x[(size_t)s * NX + i];
+    plant_rk4<NX>(xs, u[s], dt, to_mp(m));
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[(size_t)s * NX + i] = xs[i];
+}
+
+template <int NX>
+__global__ __launch_bounds__(256) void k_plant_f(int B, MP6 m, const double *x, const double *u, double *xd)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    double xs[NX], o[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) xs[i] = x[(size_t)s * NX + i];
+    plant_f<NX>(xs, u[s], to_mp(m), o);
+#pragma unroll
+    for (int i = 0; i < NX; i++) xd[(size_t)s * NX + i] = o[i];
+}
+
+static inline dim3 grid_for(int B) { return dim3((B + 255) / 256); }
+
+hipError_t launch_plant_rk4(hipStream_t st, int B, int nx, double dt, const double *mp6, double *x, const double *u)
+{
+    if (nx == 8) hipLaunchKernelGGL(k_plant_rk4<8>, grid_for(B), dim3(256), 0, st, B, dt, mp6_from_host(mp6), x, u);
+    else if (nx == 10) hipLaunchKernelGGL(k_plant_rk4<10>, grid_for(B), dim3(256), 0, st, B, dt, mp6_from_host(mp6), x, u);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_plant_f(hipStream_t st, int B, int nx, const double *mp6, const double *x, const double *u, double *xd)
+{
+    if (nx == 8) hipLaunchKernelGGL(k_plant_f<8>, grid_for(B), dim3(256), 0, st, B, mp6_from_host(mp6), x, u, xd);
+    else if (nx == 10) hipLaunchKernelGGL(k_plant_f<10>, grid_for(B), dim3(256), 0, st, B, mp6_from_host(mp6), x, u, xd);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------- EKF
+// F = I + dt*A of Dynamics.jacobian_forward_euler (continuous_dynamics.py:167-210), including its log(vx)
+// terms, the positive tf22dr and the 1/m side-force column (:151-165), which the estimator depends on.
+__device__ __forceinline__ void ekf_jacobian(const double *x, double dt, const ModelParams &mp, double *F)
+{
+#pragma unroll
+    for (int i = 0; i < 100; i++) F[i] = 0.0;
+    const double lg = log(x[4]);
+    const double cs = mp.Cf + mp.Cr, cd = mp.Cr * mp.lr - mp.Cf * mp.lf, ci = mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr;
+    const double tf11dvx = -cs / mp.m * x[5] * lg;
+    const double tf11dvy = -cs / (mp.m * x[4]);
+    const double tf12dvx = -x[6] + cd / mp.m * lg;
+    const double tf12dr = -x[4] + cd / (mp.m * x[4]);
+    const double tf1dd = -mp.Cf / mp.m;
+    const double tf21dvx = (mp.lr * mp.Cr - mp.lf * mp.Cf) / mp.Iz * x[5] * lg;
+    const double tf21dvy = (mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * x[4]);
+    const double tf22dvx = (ci / mp.Iz * x[6]) * lg;
+    const double tf22dr = ci / (mp.Iz * x[4]);
+    const double tf2dd = -(mp.Cf * mp.lf) / mp.Iz;
+#define FF(r, c) F[(r) * 10 + (c)]
+    FF(0, 2) = dt * x[4]; FF(0, 3) = dt * -x[5]; FF(0, 4) = dt * x[2]; FF(0, 5) = dt * -x[3];
+    FF(1, 2) = dt * x[5]; FF(1, 3) = dt * x[4];  FF(1, 4) = dt * x[3]; FF(1, 5) = dt * x[2];
+    FF(2, 3) = dt * -x[6]; FF(2, 6) = dt * -x[3];
+    FF(3, 2) = dt * x[6];  FF(3, 6) = dt * x[2];
+    FF(5, 4) = dt * (tf11dvx + tf12dvx); FF(5, 5) = dt * tf11dvy; FF(5, 6) = dt * tf12dr; FF(5, 7) = dt * tf1dd;
+    FF(6, 4) = dt * (tf21dvx + tf22dvx); FF(6, 5) = dt * tf21dvy; FF(6, 6) = dt * tf22dr; FF(6, 7) = dt * tf2dd;
+    FF(5, 8) = dt * (-mp.Cf / mp.m); FF(6, 8) = dt * (-(mp.Cf * mp.lf) / mp.Iz);
+    FF(5, 9) = dt * (1.0 / mp.m);
+#undef FF
+#pragma unroll
+    for (int i = 0; i < 10; i++) F[i * 10 + i] += 1.0;
+}
+
+__global__ __launch_bounds__(64) void k_ekf_jacobian(int B, double dt, MP6 m, const double *x, double *Fout)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    double xs[10], F[100];
+#pragma unroll
+    for (int i = 0; i < 10; i++) xs[i] = x[(size_t)s * 10 + i];
+    ekf_jacobian(xs, dt, to_mp(m), F);
+    for (int i = 0; i < 100; i++) Fout[(size_t)s * 100 + i] = F[i];
+}
+
+// EKF.py:38-43: x <- x + dt f(x,u) (forward Euler), F at the pre-update estimate, P <- F P F' + Q.
+// F is sparse (rows 0-3, 5, 6 carry off-diagonal terms); the products below only visit its pattern.
+__global__ __launch_bounds__(64) void k_ekf_time_update(int B, double dt, MP6 m, V10 qd, double *x, double *P,
+                                                        const double *u)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    const ModelParams mp = to_mp(m);
+    double xs[10], xd[10], F[100];
+#pragma unroll
+    for (int i = 0; i < 10; i++) xs[i] = x[(size_t)s * 10 + i];
+    plant_f<10>(xs, u[s], mp, xd);
+    ekf_jacobian(xs, dt, mp, F);
+#pragma unroll
+    for (int i = 0; i < 10; i++) x[(size_t)s * 10 + i] = xd[i] * dt + xs[i];
+    double *Pg = P + (size_t)s * 100;
+    double T[100];
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 10; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 10; k++) acc += F[i * 10 + k] * Pg[k * 10 + j];
+            T[i * 10 + j] = acc;
+        }
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 10; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 10; k++) acc += T[i * 10 + k] * F[j * 10 + k];
+            Pg[i * 10 + j] = acc + (i == j ? qd.v[i] : 0.0);
+        }
+}
+
+__constant__ int c_meas_idx[7] = {0, 1, 2, 3, 4, 6, 7};   // continuous_dynamics.py:35-45
+
+// EKF.py:45-49,65-74: K = solve(S', (P H')')' with S = H P H' + R, x += K (y - H x), P -= K H P.
+// The 7x7 system is solved by Gaussian elimination with partial pivoting (what numpy.linalg.solve does).
+__global__ __launch_bounds__(64) void k_ekf_meas_update(int B, V7 rd, double *x, double *P, const double *y, double *K_out,
+                                                        int gain_only)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    double *Pg = P + (size_t)s * 100;
+    double *xg = x + (size_t)s * 10;
+    double M[49], X[70];
+    for (int a = 0; a < 7; a++)
+        for (int b = 0; b < 7; b++)   // M = S'
+            M[a * 7 + b] = Pg[c_meas_idx[b] * 10 + c_meas_idx[a]] + (a == b ? rd.v[a] : 0.0);
+    for (int a = 0; a < 7; a++)
+        for (int i = 0; i < 10; i++) X[a * 10 + i] = Pg[i * 10 + c_meas_idx[a]];
+    for (int c = 0; c < 7; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 7; r++)
+            if (fabs(M[r * 7 + c]) > fabs(M[piv * 7 + c])) piv = r;
+        if (piv != c) {
+            for (int j = 0; j < 7; j++) { double t = M[c * 7 + j]; M[c * 7 + j] = M[piv * 7 + j]; M[piv * 7 + j] = t; }
+            for (int j = 0; j < 10; j++) { double t = X[c * 10 + j]; X[c * 10 + j] = X[piv * 10 + j]; X[piv * 10 + j] = t; }
+        }
+        for (int r = c + 1; r < 7; r++) {
+            const double f = M[r * 7 + c] / M[c * 7 + c];
+            for (int j = c; j < 7; j++) M[r * 7 + j] -= f * M[c * 7 + j];
+            for (int j = 0; j < 10; j++) X[r * 10 + j] -= f * X[c * 10 + j];
+        }
+    }
+    for (int c = 6; c >= 0; c--)
+        for (int j = 0; j < 10; j++) {
+            double acc = X[c * 10 + j];
+            for (int k = c + 1; k < 7; k++) acc -= M[c * 7 + k] * X[k * 10 + j];
+            X[c * 10 + j] = acc / M[c * 7 + c];
+        }
+    // K[i][a] = X[a][i]
+    if (K_out)
+        for (int i = 0; i < 10; i++)
+            for (int a = 0; a < 7; a++) K_out[(size_t)s * 70 + i * 7 + a] = X[a * 10 + i];
+    if (gain_only) return;
+    double innov[7];
+    for (int a = 0; a < 7; a++) innov[a] = y[(size_t)s * 7 + a] - xg[c_meas_idx[a]];
+    for (int i = 0; i < 10; i++) {
+        double acc = 0.0;
+        for (int a = 0; a < 7; a++) acc += X[a * 10 + i] * innov[a];
+        xg[i] += acc;
+    }
+    double HP[70];
+    for (int a = 0; a < 7; a++)
+        for (int j = 0; j < 10; j++) HP[a * 10 + j] = Pg[c_meas_idx[a] * 10 + j];
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 10; j++) {
+            double acc = 0.0;
+            for (int a = 0; a < 7; a++) acc += X[a * 10 + i] * HP[a * 10 + j];
+            Pg[i * 10 + j] -= acc;
+        }
+}
+
+static inline V10 v10_from_host(const double *p) { V10 m; for (int i = 0; i < 10; i++) m.v[i] = p[i]; return m; }
+static inline V7 v7_from_host(const double *p) { V7 m; for (int i = 0; i < 7; i++) m.v[i] = p[i]; return m; }
+
+hipError_t launch_ekf_time_update(hipStream_t st, int B, double dt, const double *mp6, const double *qd, double *x,
+                                  double *P, const double *u)
+{
+    hipLaunchKernelGGL(k_ekf_time_update, dim3((B + 63) / 64), dim3(64), 0, st, B, dt, mp6_from_host(mp6),
+                       v10_from_host(qd), x, P, u);
+    return hipGetLastError();
+}
+
+hipError_t launch_ekf_meas_update(hipStream_t st, int B, const double *rd, double *x, double *P, const double *y,
+                                  double *K_out, int gain_only)
+{
+    hipLaunchKernelGGL(k_ekf_meas_update, dim3((B + 63) / 64), dim3(64), 0, st, B, v7_from_host(rd), x, P, y, K_out,
+                       gain_only);
+    return hipGetLastError();
+}
+
+hipError_t launch_ekf_jacobian(hipStream_t st, int B, double dt, const double *mp6, const double *x, double *F)
+{
+    hipLaunchKernelGGL(k_ekf_jacobian, dim3((B + 63) / 64), dim3(64), 0, st, B, dt, mp6_from_host(mp6), x, F);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ planners
+// One wavefront per scenario, lane k -> waypoint k (and k + 64, ...).
+__global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const double *pose, const int *lap,
+                                               double *prev_progress, const double *target_vel, double *wp_out,
+                                               double *progress_out, double *abs_out)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const double x = pose[3 * (size_t)s], y = pose[3 * (size_t)s + 1], heading = pose[3 * (size_t)s + 2];
+    const double v = target_vel[s];
+    double p0;
+    if (mode == MODE_SKIDPAD) {
+        int lp = lap[s];
+        p0 = sk_pos2progress(x, y, lp);
+        if (prev_progress[s] > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(x, y, lp); }   // path_planning.py:227-230
+    } else
+        p0 = x;
+    const double ch = cos(heading), sh = sin(heading);
+    for (int k = lane; k <= N; k += WAVE) {
+        double o[4];
+        const double q = waypoint_progress(p0, v, dt, k);
+        if (mode == MODE_SKIDPAD) sk_pose(q, o);
+        else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+        if (abs_out) {
+            double *w = abs_out + ((size_t)s * (N + 1) + k) * 4;
+            w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+        }
+        to_car_frame(o, x, y, ch, sh);
+        double *w = wp_out + ((size_t)s * (N + 1) + k) * 4;
+        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (progress_out) progress_out[s] = p0;
+        if (mode == MODE_SKIDPAD) prev_progress[s] = p0;                                       // path_planning.py:251
+    }
+}
+
+hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const double *pose, const int *lap,
+                               double *prev_progress, const double *target_vel, double *wp_out, double *progress_out)
+{
+    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_SKIDPAD, N, dt, pose, lap, prev_progress,
+                       target_vel, wp_out, progress_out, (double *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
+                            double *wp_out, double *progress_out, double *abs_out)
+{
+    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_STEP, N, dt, pose, (const int *)nullptr,
+                       (double *)nullptr, target_vel, wp_out, progress_out, abs_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ statistics
+// Single-block reduction of the per-scenario solver records into 16 doubles (sums and maxima).
+__global__ __launch_bounds__(256) void k_stats(int B, const double *stat, const int *iters, const int *status,
+                                               double *out16)
+{
+    __shared__ double sh[8][256];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = threadIdx.x; s < B; s += 256) {
+        const double *q = stat + 4 * (size_t)s;
+        acc[0] += 1.0; acc[1] += iters[s]; acc[2] += (status[s] != 0); acc[3] += q[2]; acc[4] += q[3];
+        acc[5] = fmax(acc[5], q[3]);
+        if (q[2] != 0.0) { acc[6] = fmax(acc[6], q[0]); acc[7] = fmax(acc[7], q[1]); }
+    }
+    for (int c = 0; c < 8; c++) sh[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int w = 128; w; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int c = 0; c < 8; c++)
+                sh[c][threadIdx.x] = (c < 5) ? sh[c][threadIdx.x] + sh[c][threadIdx.x + w]
+                                             : fmax(sh[c][threadIdx.x], sh[c][threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) out16[threadIdx.x] = threadIdx.x < 8 ? sh[threadIdx.x][0] : 0.0;
+}
+
+hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, double *out16)
+{
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, B, stat, iters, status, out16);
+    return hipGetLastError();
+}
+
+}  // namespace mpc

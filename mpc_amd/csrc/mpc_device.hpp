@@ -1,0 +1,155 @@
+// Device-side building blocks shared by the kernels of libmpc_amd (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpc {
+
+constexpr int WAVE = 64;
+
+// Uniform broadcast of lane `src` (wave-uniform index) through v_readlane: the result lives in SGPRs.
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v = fmin(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+// inclusive scans over the 64 lanes (callers zero the lanes that do not take part)
+__device__ __forceinline__ double incl_prefix(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ double incl_suffix(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double t = __shfl_down(v, d);
+        if (lane + d < WAVE) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- model pieces (uniform or per lane)
+struct ModelParams { double m, Iz, lf, lr, Cf, Cr; };
+
+// Lateral coefficients of the controller model, with the whole bracket of a12 divided
+// (LMPC2.py:133-149, LPVMPC.py:131-147, OFLMPC2.py:138-155).
+__device__ __forceinline__ void lat_coeffs(const ModelParams &mp, double vx, double eps, double &a11, double &a12,
+                                           double &a21, double &a22)
+{
+    a11 = -(mp.Cf + mp.Cr) / (mp.m * vx + eps);
+    a12 = (-vx + (mp.Cr * mp.lr - mp.Cf * mp.lf)) / (mp.m * vx + eps);
+    a21 = (mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * vx + eps);
+    a22 = -(mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr) / (mp.Iz * vx + eps);
+}
+
+// Plant right-hand side (continuous_dynamics.py:90-124); x has NX = 8 or 10 entries.
+template <int NX>
+__device__ __forceinline__ void plant_f(const double *x, double u, const ModelParams &mp, double *xd)
+{
+    double sd = 0.0, fd = 0.0;
+    if (NX == 10) { sd = x[8]; fd = x[9]; }
+    xd[0] = x[2] * x[4] - x[3] * x[5];
+    xd[1] = x[3] * x[4] + x[2] * x[5];
+    xd[2] = -x[6] * x[3];
+    xd[3] = x[6] * x[2];
+    xd[4] = 0.0;
+    xd[5] = ((-(mp.Cf + mp.Cr) / (mp.m * x[4]) * x[5] +
+              (-x[4] + (mp.Cr * mp.lr - mp.Cf * mp.lf) / (mp.m * x[4])) * x[6]) -
+             mp.Cf / mp.m * (x[7] + sd) + fd);
+    xd[6] = ((mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * x[4]) * x[5] -
+             (mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr) / (mp.Iz * x[4]) * x[6] -
+             (mp.Cf * mp.lf) / mp.Iz * (x[7] + sd));
+    xd[7] = u;
+    if (NX == 10) { xd[8] = 0.0; xd[9] = 0.0; }
+}
+
+// Classic RK4 with the input held (continuous_dynamics.py:126-133).
+template <int NX>
+__device__ __forceinline__ void plant_rk4(double *x, double u, double dt, const ModelParams &mp)
+{
+    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
+    plant_f<NX>(x, u, mp, k1);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k1[i];
+    plant_f<NX>(t, u, mp, k2);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k2[i];
+    plant_f<NX>(t, u, mp, k3);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt * k3[i];
+    plant_f<NX>(t, u, mp, k4);
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+}
+
+// ---------------------------------------------------------------- planners
+constexpr double SK_R = 9.125, SK_CENTER = 16.75;
+constexpr double PI = 3.14159265358979323846;
+constexpr double SK_LAP = 2 * SK_R * PI;
+
+// utils/path_planning.py:196-209
+__device__ __forceinline__ double sk_pos2progress(double x, double y, int lap)
+{
+    if (lap == 0) return x;
+    if (lap > 0 && lap < 3) return (-atan2(x - SK_CENTER, -SK_R - y) + PI) * SK_R + (lap - 1) * SK_LAP + SK_CENTER;
+    if (lap > 2 && lap < 5) return (atan2(SK_CENTER - x, y - SK_R) + PI) * SK_R + (lap - 1) * SK_LAP + SK_CENTER;
+    return x + 4 * SK_LAP;
+}
+
+// utils/path_planning.py:131-167; "a // b > 0" with b > 0 is "a >= b".
+__device__ __forceinline__ void sk_pose(double q, double *o)
+{
+    if (q - SK_CENTER >= 4 * SK_LAP) { o[0] = q - 4 * SK_LAP; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+    else if (q - SK_CENTER >= 2 * SK_LAP) {
+        double a = (q - SK_CENTER - 2 * SK_LAP) / SK_R, b = (q - SK_CENTER) / SK_R;
+        o[0] = SK_CENTER + sin(a) * SK_R; o[1] = SK_R - cos(a) * SK_R; o[2] = cos(b); o[3] = sin(b);
+    } else if (q - SK_CENTER > 0) {
+        double b = (q - SK_CENTER) / SK_R;
+        o[0] = SK_CENTER + sin(b) * SK_R; o[1] = -SK_R + cos(b) * SK_R; o[2] = cos(b); o[3] = -sin(b);
+    } else { o[0] = q; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+}
+
+// translate by the car position and right-multiply by [[c,-s],[s,c]] (path_planning.py:253-260)
+__device__ __forceinline__ void to_car_frame(double *o, double x, double y, double ch, double sh)
+{
+    double px = o[0] - x, py = o[1] - y, hx = o[2], hy = o[3];
+    o[0] = px * ch + py * sh;
+    o[1] = -px * sh + py * ch;
+    o[2] = hx * ch + hy * sh;
+    o[3] = -hx * sh + hy * ch;
+}
+
+// progress of waypoint k: p0 + cumsum(speeds[:-1])[k-1] * dt with np.cumsum's sequential accumulation
+__device__ __forceinline__ double waypoint_progress(double p0, double v, double dt, int k)
+{
+    if (k == 0) return p0;
+    double cs = v;
+    for (int i = 1; i < k; i++) cs += v;
+    return p0 + cs * dt;
+}
+
+}  // namespace mpc

@@ -1,0 +1,52 @@
+// Internal declarations shared by the translation units of libmpc_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/mpc_amd.h"
+
+// Horizons with a compiled solver (the Newton-matrix row of a lane lives in N statically indexed registers).
+#ifndef MPC_HORIZONS
+#define MPC_HORIZONS(X) X(10) X(20) X(30) X(40) X(50) X(64)
+#endif
+
+namespace mpc {
+
+enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2 };
+
+struct DevCfg {
+    int kind, N, lpv_lin_prev, max_iter;
+    double dt, eps, max_steering, max_rate, tol_mu, tol_res;
+    double mp[6];
+    double w[7];
+    double We[36];
+};
+
+struct SolveArgs {
+    int mode, B;
+    const double *x0, *wp, *p, *d_hat;                    // MODE_SOLVE inputs
+    double *state; int *lap; double *prev_progress;       // closed-loop state (updated)
+    const double *target_vel;
+    double *lin_x, *lin_u;                                // LPV linearisation memory (updated)
+    const double *mp_scen;                                // optional per-scenario model parameters
+    double *Hws;                                          // workspace: B * N * N condensed Hessians
+    double *U_out, *traj_out, *u0_out, *wp_out;
+    int *status_out, *iters_out;
+    double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
+};
+
+hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
+bool horizon_supported(int N);
+
+hipError_t launch_plant_rk4(hipStream_t st, int B, int nx, double dt, const double *mp6, double *x, const double *u);
+hipError_t launch_plant_f(hipStream_t st, int B, int nx, const double *mp6, const double *x, const double *u, double *xd);
+hipError_t launch_ekf_time_update(hipStream_t st, int B, double dt, const double *mp6, const double *qd, double *x,
+                                  double *P, const double *u);
+hipError_t launch_ekf_meas_update(hipStream_t st, int B, const double *rd, double *x, double *P, const double *y,
+                                  double *K_out, int gain_only);
+hipError_t launch_ekf_jacobian(hipStream_t st, int B, double dt, const double *mp6, const double *x, double *F);
+hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const double *pose, const int *lap,
+                               double *prev_progress, const double *target_vel, double *wp_out, double *progress_out);
+hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
+                            double *wp_out, double *progress_out, double *abs_out);
+hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, double *out16);
+
+}  // namespace mpc
