@@ -65,6 +65,15 @@ const char *mpc_last_error(const mpc_handle *h); /* h may be NULL: last error of
 /* Optional per-scenario model parameters mp[B][6] (tyre / mass sweeps); NULL restores cfg.mp. */
 int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario);
 
+/* Fixed-model cache for the linear controllers (kind L / OFL): condenses the horizon once for "every stage at
+ * speed vx" (the skidpad planner hands the controller a constant speed profile, path_planning.py:238-240) and
+ * caches H and inv(H) times every way the gradient depends on the step's data.  Scenarios whose speed profile
+ * is not exactly vx still take the per-scenario condensing path inside the same launch, unless `exclusive` is
+ * set: then the caller promises that every scenario runs at vx, a leaner kernel without the per-scenario path is
+ * launched, and a scenario that breaks the promise is not solved but reported with status 3.  vx = NaN switches
+ * the cache off.  Plays the role of the one-time QP data set-up inside AcadosOcpSolver(ocp) (LMPC2.py:94). */
+int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
+
 /* optimize(): the yref/p set loop + solve_for_x0 + x/u get loop of LMPC2.py:296-347,
  * OFLMPC2.py:315-367, LPVMPC.py:254-341, for B scenarios.
  *   x0      [B][7]  reduced state [pose(4), vy, r, delta]
@@ -83,6 +92,16 @@ int mpc_closed_loop_step(mpc_handle *h, void *stream, int B, int planner, double
                          double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
                          double *u0_out, double *wp_out, double *traj_out, double *U_out, int *status_out,
                          int *iters_out);
+
+/* nsteps fused closed-loop steps in ONE launch (StepSimulator.simulate(n_steps), simulator.py:172-204, and a
+ * for-loop over SkidpadSimulator.step): scenarios are independent, so each wavefront advances its scenario
+ * through all steps with the plant state in registers and no host round trip.  iters_out receives the
+ * interior-point iterations summed over the steps, status_out the worst status; u_hist [nsteps][B] and
+ * x_hist [nsteps][B][8] (plant state after each step) are optional.  wp/traj/U outputs hold the last step. */
+int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nsteps, double *state, int *lap,
+                        double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
+                        double *u0_out, double *wp_out, double *traj_out, double *U_out, double *u_hist,
+                        double *x_hist, int *status_out, int *iters_out);
 
 /* Dynamics.single_track_model / rk4_integraton (continuous_dynamics.py:90-133): x [B][nx], nx = 8 or 10. */
 int mpc_plant_rk4(void *stream, int B, int nx, double dt, const double *mp6_host, double *x, const double *u);

@@ -13,6 +13,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libmpc_amd.so")
 SOURCES = ["mpc_solver.hip", "mpc_aux.hip", "mpc_abi.hip"]
 HEADERS = ["mpc_device.hpp", "mpc_kernels.h", os.path.join("..", "..", "include", "mpc_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# Machine LICM hoists the literal constants of the inlined math routines out of the in-kernel step loop and then
+# spills them to scratch; rematerialising them in place keeps the per-step hot path free of scratch traffic.
+EXTRA_FLAGS = {"mpc_solver.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _hipcc() -> str:
@@ -40,7 +43,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

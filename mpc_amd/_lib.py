@@ -30,8 +30,10 @@ _SIGS = {
     "mpc_destroy": ([_vp], None),
     "mpc_last_error": ([_vp], C.c_char_p),
     "mpc_set_model_params": ([_vp, _vp], C.c_int),
+    "mpc_condense_fixed": ([_vp, _vp, C.c_double, C.c_int], C.c_int),
     "mpc_solve_only": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
     "mpc_closed_loop_step": ([_vp, _vp, C.c_int, C.c_int] + [_vp] * 12, C.c_int),
+    "mpc_closed_loop_run": ([_vp, _vp, C.c_int, C.c_int, C.c_int] + [_vp] * 14, C.c_int),
     "mpc_plant_rk4": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _vp, _vp], C.c_int),
     "mpc_plant_f": ([_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp], C.c_int),
     "mpc_ekf_time_update": ([_vp, C.c_int, C.c_double, _dp, _dp, _vp, _vp, _vp], C.c_int),

@@ -15,7 +15,8 @@ from .controllers import LOcp, LPVOcp
 class _ClosedLoopBatch:
     planner = _lib.PLANNER_SKIDPAD
 
-    def __init__(self, N, Tf, starting_states, starting_laps=None, model="L", device=None, target_vel=None, **ctl_kw):
+    def __init__(self, N, Tf, starting_states, starting_laps=None, model="L", device=None, target_vel=None,
+                 fixed_model_cache=True, **ctl_kw):
         states = np.ascontiguousarray(starting_states, dtype=np.float64)
         if states.ndim != 2 or states.shape[1] != 8:
             raise ValueError("starting_states must be (B, 8): [x, y, cos, sin, vx, vy, r, delta]")
@@ -34,6 +35,8 @@ class _ClosedLoopBatch:
         self.prev_progress = torch.zeros(B, dtype=torch.float64, device=dev)
         tv = states[:, 4] if target_vel is None else np.broadcast_to(np.asarray(target_vel, dtype=np.float64), (B,))
         self.target_vel = _dev.f64(tv, dev)               # SkidpadPlanner(target_vel=starting_velocity[0])
+        if model == "L" and fixed_model_cache and np.all(tv == tv[0]):
+            self.ocp.condense_fixed(float(tv[0]), exclusive=True)   # fixed A,B: condense once, not per scenario and step
         self.u0 = torch.zeros(B, dtype=torch.float64, device=dev)
         self.status = torch.zeros(B, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -63,14 +66,24 @@ class _ClosedLoopBatch:
         _lib.check(rc, s.h, "mpc_closed_loop_step")
         return self.u0
 
+    def run(self, n_steps: int, record: bool = False):
+        """n closed-loop steps in ONE kernel launch (each wavefront carries its scenario through all steps).
+        Returns (states (n,B,8), inputs (n,B)) device tensors when record is set, else None.  self.iters then
+        holds the interior-point iterations summed over the steps."""
+        dev = self.device
+        xs = torch.empty((n_steps, self.B, 8), dtype=torch.float64, device=dev) if record else None
+        us = torch.empty((n_steps, self.B), dtype=torch.float64, device=dev) if record else None
+        s = self.ocp.solver
+        rc = s._lib.mpc_closed_loop_run(
+            s.h, _dev.stream_ptr(dev), self.B, self.planner, int(n_steps), _dev.ptr(self.state), _dev.ptr(self.lap),
+            _dev.ptr(self.prev_progress), _dev.ptr(self.target_vel), _dev.ptr(self.lin_x), _dev.ptr(self.lin_u),
+            _dev.ptr(self.u0), None, None, None, _dev.ptr(us), _dev.ptr(xs), _dev.ptr(self.status), _dev.ptr(self.iters))
+        _lib.check(rc, s.h, "mpc_closed_loop_run")
+        return (xs, us) if record else None
+
     def simulate(self, n_steps: int):
         """n closed-loop steps; returns (states (n,B,8), inputs (n,B)) as device tensors."""
-        xs = torch.empty((n_steps, self.B, 8), dtype=torch.float64, device=self.device)
-        us = torch.empty((n_steps, self.B), dtype=torch.float64, device=self.device)
-        for i in range(n_steps):
-            us[i] = self.step()
-            xs[i] = self.state
-        return xs, us
+        return self.run(n_steps, record=True)
 
 
 class SkidpadBatch(_ClosedLoopBatch):

@@ -226,6 +226,13 @@ class _CondensedMpc:
             raise RuntimeError(f"MPC solve failed with status {st}")
         return 0, traj, U.reshape(self.N, 1)
 
+    def condense_fixed(self, vx, exclusive: bool = False):
+        """Cache the condensed problem for a constant speed profile (None switches the cache off).  With
+        `exclusive` the caller promises that every scenario runs at vx (status 3 flags a broken promise)."""
+        v = float("nan") if vx is None else float(vx)
+        rc = self.solver._lib.mpc_condense_fixed(self.solver.h, _dev.stream_ptr(self.device), v, int(bool(exclusive)))
+        _lib.check(rc, self.solver.h, "mpc_condense_fixed")
+
     def stats(self) -> dict:
         out = np.zeros(16)
         rc = self.solver._lib.mpc_get_stats(self.solver.h, _dev.stream_ptr(self.device), _lib.hptr(out))

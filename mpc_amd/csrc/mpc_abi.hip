@@ -14,6 +14,10 @@ struct mpc_handle {
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     double *mp_scen = nullptr;   // optional B * 6
     double *stats16 = nullptr;   // device result of the statistics reduction
+    double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
+    double sh_vx = 0.0;
+    int sh_mask = 0;
+    bool sh_on = false, sh_exclusive = false;
     const int *last_iters = nullptr, *last_status = nullptr;
     int last_B = 0;
     std::string err;
@@ -83,6 +87,7 @@ void mpc_destroy(mpc_handle *h)
     if (!h) return;
     (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen);
+    (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     delete h;
 }
 
@@ -94,6 +99,37 @@ int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
     if (!h->mp_scen) HIP_TRY(h, hipMalloc(&h->mp_scen, bytes));
     HIP_TRY(h, hipMemcpy(h->mp_scen, mp_per_scenario, bytes, hipMemcpyDeviceToDevice));
     return MPC_OK;
+}
+
+int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
+{
+    if (!h) return MPC_EINVAL;
+    if (h->cfg.kind == MPC_KIND_LPV) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV model is re-linearised every step");
+    if (!(vx == vx)) { h->sh_on = false; return MPC_OK; }   // NaN switches the cache off
+    const size_t N = (size_t)h->cfg.N;
+    if (!h->sh_H) {
+        HIP_TRY(h, hipMalloc(&h->sh_H, N * N * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->sh_Kref, 3 * N * N * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->sh_Kx, 5 * N * sizeof(double)));
+    }
+    HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, (hipStream_t)stream));
+    h->sh_vx = vx;
+    h->sh_mask = 0;
+    for (int c = 0; c < 3; c++) {
+        bool used = h->cfg.w[c] != 0.0;
+        for (int d = 0; d < 6; d++) used = used || h->cfg.We[d * 6 + c] != 0.0 || h->cfg.We[c * 6 + d] != 0.0;
+        if (used) h->sh_mask |= 1 << c;
+    }
+    h->sh_on = true;
+    h->sh_exclusive = exclusive != 0;
+    return MPC_OK;
+}
+
+static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
+{
+    if (h->sh_on && !h->mp_scen) {
+        a.sh_H = h->sh_H; a.sh_Kref = h->sh_Kref; a.sh_Kx = h->sh_Kx; a.sh_vx = h->sh_vx; a.sh_mask = h->sh_mask; a.sh_exclusive = h->sh_exclusive ? 1 : 0;
+    }
 }
 
 static int check_batch(mpc_handle *h, int B, const char *who)
@@ -111,21 +147,37 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_solve_only: x0, wp, p and U_out are required");
     if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_solve_only: LPV needs lin_x and lin_u");
     mpc::SolveArgs a = {};
-    a.mode = mpc::MODE_SOLVE; a.B = B; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
+    a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.U_out = U_out; a.traj_out = traj_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
+    attach_cache(h, a);
     h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
     HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
     return MPC_OK;
 }
+
+int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nsteps, double *state, int *lap,
+                        double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
+                        double *u0_out, double *wp_out, double *traj_out, double *U_out, double *u_hist,
+                        double *x_hist, int *status_out, int *iters_out);
 
 int mpc_closed_loop_step(mpc_handle *h, void *stream, int B, int planner, double *state, int *lap,
                          double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
                          double *u0_out, double *wp_out, double *traj_out, double *U_out, int *status_out,
                          int *iters_out)
 {
+    return mpc_closed_loop_run(h, stream, B, planner, 1, state, lap, prev_progress, target_vel, lin_x, lin_u, u0_out,
+                               wp_out, traj_out, U_out, nullptr, nullptr, status_out, iters_out);
+}
+
+int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nsteps, double *state, int *lap,
+                        double *prev_progress, const double *target_vel, double *lin_x, double *lin_u,
+                        double *u0_out, double *wp_out, double *traj_out, double *U_out, double *u_hist,
+                        double *x_hist, int *status_out, int *iters_out)
+{
     if (int rc = check_batch(h, B, "mpc_closed_loop_step")) return rc;
+    if (nsteps < 1) return fail(h, MPC_EINVAL, "mpc_closed_loop_run: nsteps must be >= 1");
     if (planner != MPC_PLANNER_SKIDPAD && planner != MPC_PLANNER_STEP) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: unknown planner");
     if (!state || !target_vel || !u0_out) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: state, target_vel and u0_out are required");
     if (planner == MPC_PLANNER_SKIDPAD && (!lap || !prev_progress)) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: skidpad planner needs lap and prev_progress");
@@ -133,11 +185,13 @@ int mpc_closed_loop_step(mpc_handle *h, void *stream, int B, int planner, double
     if (h->cfg.kind == MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: the OFL loop runs on the estimate; use mpc_solve_only with the EKF entry points");
     mpc::SolveArgs a = {};
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
+    a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist;
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
+    attach_cache(h, a);
     h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
     HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
     return MPC_OK;

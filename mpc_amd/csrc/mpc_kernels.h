@@ -22,6 +22,8 @@ struct DevCfg {
 
 struct SolveArgs {
     int mode, B;
+    int nsteps;                                           // closed-loop modes: steps advanced by one launch
+    double *u_hist, *x_hist;                              // optional [nsteps][B] inputs / [nsteps][B][8] states
     const double *x0, *wp, *p, *d_hat;                    // MODE_SOLVE inputs
     double *state; int *lap; double *prev_progress;       // closed-loop state (updated)
     const double *target_vel;
@@ -31,9 +33,17 @@ struct SolveArgs {
     double *U_out, *traj_out, *u0_out, *wp_out;
     int *status_out, *iters_out;
     double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
+    // Fixed-model cache (every scenario at speed sh_vx with the handle's model parameters); NULL = off.
+    const double *sh_H;      // [N][N] condensed Hessian
+    const double *sh_Kref;   // [3][N][N]: inv(H) * d g / d ref_c(stage k+1), stored [c][k][i]
+    const double *sh_Kx;     // [5][N]: -inv(H) * g for unit vy, r, delta, the constant term, unit d_hat
+    double sh_vx;
+    int sh_exclusive;        // caller promises every scenario runs at sh_vx: launch the fixed-model-only kernel
+    int sh_mask;             // bit c set: reference component c (x, y, sin psi) carries weight
 };
 
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
 bool horizon_supported(int N);
 
 hipError_t launch_plant_rk4(hipStream_t st, int B, int nx, double dt, const double *mp6, double *x, const double *u);

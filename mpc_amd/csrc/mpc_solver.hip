@@ -1,25 +1,62 @@
 // Wave-per-scenario condensed MPC step for gfx950.
 //
 // One 64-lane wavefront owns one scenario; lane k owns stage k of the horizon (decision variable u_k,
-// column k of the prediction matrix, row k of the condensed Hessian).  The kernel
+// column k of the prediction matrix, row k of the condensed Hessian).  Per closed-loop step the wave
 //   1. plans the car-frame reference (closed-loop modes) or reads it (optimize() mode),
 //   2. linearises/discretises the controller model per stage,
-//   3. condenses the OCP into  min 1/2 U'HU + g'U,  |u_k| <= umax,  |delta_0 + dt*sum_{j<=k} u_j| <= dmax,
-//   4. solves it exactly: unconstrained solve first, Mehrotra predictor-corrector interior point only if a
+//   3. condenses the OCP into  min 1/2 U'HU + g'U,  |u_k| <= umax,  |delta_0 + dt*sum_{j<=k} u_j| <= dmax
+//      (per scenario, or through the fixed-model cache when every stage runs at one cached speed),
+//   4. solves it exactly: unconstrained minimiser first, Mehrotra predictor-corrector interior point only if a
 //      bound is violated; every Newton system K = H + A'DA is factorised K = L D L' with row k of K held in
-//      the registers of lane k and pivots broadcast through v_readlane,
-//   5. rolls the prediction out, advances the plant with RK4 and does the lap bookkeeping.
+//      the registers of lane k and the pivot column broadcast through v_readlane,
+//   5. rolls the prediction out, advances the plant with RK4 and does the lap bookkeeping,
+// and repeats for `nsteps` steps inside one launch (scenarios are independent, so no grid-wide dependency).
+//
+// Two kernel variants: GENERAL (one wave per workgroup, per-scenario condensing available) and the
+// fixed-model-only variant (four waves per workgroup sharing the cached matrices in LDS, 2 workgroups per CU).
 //
 // Reference behaviour restated (file:line of the reference checkout):
 //   LMPC2.py:114-168 / OFLMPC2.py:118-181 / LPVMPC.py:110-171  stage model      -> stage_model()
 //   LMPC2.py:220-260, LPVMPC.py:191-226, OFLMPC2.py:239-279    LINEAR_LS cost   -> condense()
-//   LMPC2.py:196-210                                           bounds           -> ipm
-//   LMPC2.py:296-347, LPVMPC.py:254-341, OFLMPC2.py:315-367    optimize()       -> k_mpc mode 0
-//   skidpad_simulator.py:101-135, simulator.py:178-202         closed loop      -> k_mpc mode 1/2
+//   LMPC2.py:196-210                                           bounds           -> interior_point()
+//   LMPC2.py:296-347, LPVMPC.py:254-341, OFLMPC2.py:315-367    optimize()       -> k_mpc MODE_SOLVE
+//   skidpad_simulator.py:101-135, simulator.py:178-202         closed loop      -> k_mpc MODE_SKIDPAD / MODE_STEP
 #include "mpc_device.hpp"
 #include "mpc_kernels.h"
 
+// Linear algebra below may contract a*b+c; the plant and planner code in mpc_device.hpp is compiled without
+// contraction (command line) so that it rounds like the numpy expressions it restates.
+#pragma clang fp contract(fast)
+
 namespace mpc {
+
+// LDS hand-off between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
+// has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave-uniform copy of a pointer that the compiler cannot see through: the loads behind it are neither treated
+// as per-lane addressed nor hoisted out of the loop the call sits in.
+__device__ __forceinline__ const double *opaque_uniform(const double *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const double *)(((unsigned long long)hi << 32) | lo);
+}
+
+// 1/x to ~1 ulp: hardware estimate plus two Newton steps (the pivots of an SPD factorisation are never 0/inf)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 template <int N>
@@ -36,14 +73,17 @@ struct Newton {
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const double c = row[k];                 // column k of the trailing matrix, one entry per lane
-            const double dk = bcast(c, k);
-            const double inv = 1.0 / dk;
+            const double inv = fast_rcp(bcast(c, k));
             const bool below = lane > k;
             const double l = below ? c * inv : 0.0;
             if (lane == k) dinv = inv;
 #pragma unroll
-            for (int j = k + 1; j < N; j++) row[j] = fma(-l, bcast(c, j), row[j]);
+            for (int j = k + 1; j < N; j++) {
+                row[j] = fma(-l, bcast(c, j), row[j]);
+                if (((j - k) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep readlane results (SGPRs) short-lived
+            }
             if (below) row[k] = l;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -54,33 +94,297 @@ struct Newton {
 #pragma unroll
         for (int k = 0; k < N - 1; k++) {
             const double wk = bcast(w, k);
-            w = fma(-(lane > k ? row[k] : 0.0), wk, w);
+            w = fma(-row[k], lane > k ? wk : 0.0, w);   // mask the broadcast value, not the row entry: a masked copy
+                                                        // of the row is loop-invariant and would be hoisted into 2N registers
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = N - 1; k > 0; k--) {
             const double xk = bcast(w * dinv, k);
-            w = fma(-(lane < k ? row[k] : 0.0), xk, w);
+            w = fma(-row[k], lane < k ? xk : 0.0, w);
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         return w * dinv;
     }
 };
 
-struct StageRow { double e02, e03, e12, e13, f33, f34, f43, f44, c0, c1; };
 constexpr int STAGE_W = 10;
 
-// ------------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(WAVE) void k_mpc(const DevCfg cfg, const SolveArgs a)
+// Forward-Euler stage matrices of the controller model, as 10 scalars (the rest of A_k is structural):
+//   px+ = px + e02 psi + e03 vy + c0      py+ = py + e12 psi + e13 vy + c1      psi+ = psi + dt r
+//   vy+ = f33 vy + f34 r + f35 delta (+ dt d_hat)      r+ = f43 vy + f44 r + f45 delta      delta+ = delta + dt u
+__device__ __forceinline__ void stage_model(const DevCfg &cfg, const ModelParams &mp, double vx, const double *lx, int N,
+                                            int k, double *st)
 {
-    const int s = blockIdx.x;
-    const int lane = threadIdx.x;
+    const double dt = cfg.dt;
+    double a11, a12, a21, a22;
+    lat_coeffs(mp, vx, cfg.eps, a11, a12, a21, a22);
+    st[4] = 1.0 + dt * a11; st[5] = dt * a12; st[6] = dt * a21; st[7] = 1.0 + dt * a22;
+    if (cfg.kind == MPC_KIND_LPV) {
+        // x+ = x + dt (J(xb)(x - xb) + B (u - ub) + f(xb, vx, ub)), LPVMPC.py:125-171.  Linearisation point per
+        // LPVMPC.py:260-297: "reference" takes ref_points[i,3], a column that is always 0, as heading;
+        // "prev_iter" takes the previous solution shifted by one stage.
+        const double psib = cfg.lpv_lin_prev ? lx[2 * (N + 1) + k + 1] : 0.0;
+        const double vyb = lx[3 * (N + 1) + k + 1];
+        const double sn = sin(psib), co = cos(psib);
+        const double J02 = -vx * sn - vyb * co, J03 = -sn, J12 = vx * co - vyb * sn, J13 = co;
+        st[0] = dt * J02; st[1] = dt * J03; st[2] = dt * J12; st[3] = dt * J13;
+        st[8] = dt * ((vx * co - vyb * sn) - (J02 * psib + J03 * vyb));
+        st[9] = dt * ((vx * sn + vyb * co) - (J12 * psib + J13 * vyb));
+    } else {
+        st[0] = 0.0; st[1] = 0.0; st[2] = dt * vx; st[3] = dt;          // LMPC2.py:127-129
+        st[8] = dt * vx; st[9] = 0.0;
+    }
+}
+
+// Condensing sweep over the horizon.  Lane j carries column j of the prediction matrix, v = d x_k / d u_j, and
+// NF free responses (uniform over the wave).  Per stage k = 1..N it accumulates
+//   g[f]   += v' W_k (xf[f] - ref_k)            gradient contribution of free response f
+//   Hrow[i] += (W_k v_i)' v_j  for every i      row/column j of H = Gamma' W Gamma
+// with W_k = dt*diag(w) for k < N and the dense terminal weight at k = N.  The weighted columns W_k v_i are
+// exchanged through LDS (s_wv).  gref_out (optional) receives (W_k v)[c], c = 0..2: minus d g / d ref_c(k).
+// s_ref is laid out [c][k] with row length N + 1.
+template <int N, int NF>
+__device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const double *s_stage, const double *s_ref,
+                                         double *s_wv, const double *s_We, const double (&wq)[6], double f35, double f45,
+                                         const double (&c01s)[NF], const double (&c3)[NF], double (&xf)[NF][6],
+                                         double *Hrow, double (&g)[NF], double *gref_out)
+{
+    const double dt = cfg.dt;
+    const bool valid = lane < N;
+#pragma unroll
+    for (int i = 0; i < N; i++) Hrow[i] = 0.0;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int k = 1; k <= N; k++) {
+        const double *st = &s_stage[(k - 1) * STAGE_W];
+        const double e02 = st[0], e03 = st[1], e12 = st[2], e13 = st[3], f33 = st[4], f34 = st[5], f43 = st[6],
+                     f44 = st[7], c0 = st[8], c1 = st[9];
+#pragma unroll
+        for (int f = 0; f < NF; f++) {   // free responses x_k = A_{k-1} x_{k-1} + c_{k-1}
+            double *x = xf[f];
+            const double n0 = x[0] + e02 * x[2] + e03 * x[3] + c01s[f] * c0;
+            const double n1 = x[1] + e12 * x[2] + e13 * x[3] + c01s[f] * c1;
+            const double n2 = x[2] + dt * x[4];
+            const double n3 = f33 * x[3] + f34 * x[4] + f35 * x[5] + c3[f];
+            const double n4 = f43 * x[3] + f44 * x[4] + f45 * x[5];
+            x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3; x[4] = n4;
+        }
+        {   // column `lane` of the prediction matrix at stage k
+            const double n0 = v[0] + e02 * v[2] + e03 * v[3];
+            const double n1 = v[1] + e12 * v[2] + e13 * v[3];
+            const double n2 = v[2] + dt * v[4];
+            const double n3 = f33 * v[3] + f34 * v[4] + f35 * v[5];
+            const double n4 = f43 * v[3] + f44 * v[4] + f45 * v[5];
+            v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3; v[4] = n4;
+            if (lane == k - 1) { v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0; v[4] = 0; v[5] = dt; }
+        }
+        double wv[6];
+        if (k < N) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) wv[c] = wq[c] * v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double t = 0.0;
+#pragma unroll
+                for (int d = 0; d < 6; d++) t = fma(s_We[d * 6 + c], v[d], t);   // (We' v)[c]; We is symmetric
+                wv[c] = t;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            double err[6] = {xf[f][0], xf[f][1], xf[f][2], xf[f][3], xf[f][4], xf[f][5]};
+            // the LPV terminal reference stays at the constructor's zeros (LPVMPC.py:220-221)
+            if (s_ref && f == 0 && !(k == N && cfg.kind == MPC_KIND_LPV)) {
+                err[0] -= s_ref[k]; err[1] -= s_ref[(N + 1) + k]; err[2] -= s_ref[2 * (N + 1) + k];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) g[f] = fma(wv[c], err[c], g[f]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s_wv[c * N + lane] = wv[c];
+            if (gref_out) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) gref_out[((size_t)c * N + (k - 1)) * N + lane] = wv[c];
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            if (k == N || wq[c] != 0.0) {
+                const double vc = v[c];
+#pragma unroll
+                for (int i = 0; i < N; i++) Hrow[i] = fma(s_wv[c * N + i], vc, Hrow[i]);
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mehrotra predictor-corrector on  G U + t = h,  G = [A; -A],  A = [I; dt * prefix-sum].
+// H is read from memory (Hm[j*N + lane], symmetric); returns the solver status (0 converged, 2 iteration cap).
+//
+// Deliberately NOT inlined: it runs on the minority of steps whose unconstrained minimiser violates a bound, and
+// as a real call its ~250 registers (the Newton-matrix row alone is 2N) stay out of the register allocation of
+// the per-step hot path; the caller's live state is saved around the call only when the call happens.
+struct IpmParams { double dt, umax, dmax, tol_mu, tol_res; int max_iter; };
+struct IpmResult { double U, mu, res; int iters, status; };
+
+template <int N>
+__device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double xh5)
+{
+    Newton<N> nt;
+    double U, mu, res;
+    int iters;
+    const bool valid = lane < N, validd = lane < N - 1;
+    const double dt = prm.dt, dt2 = dt * dt;
+    const double umax = prm.umax, dmax = prm.dmax;
+    const double up_d = dmax - xh5, lo_d = -dmax - xh5;
+    const double gscale = fmax(1.0, wave_max(fabs(g)));
+    double tpu, tmu, lpu = 1.0, lmu = 1.0, tpd, tmd, lpd = 1.0, lmd = 1.0;
+    U = 0.0;
+    tpu = umax; tmu = umax;
+    tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax);
+    if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
+    if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
+    const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
+    double res_prev = 1e300;
+    int status = 0;
+    iters = 0;
+#pragma unroll 1
+    for (;;) {
+        // H is re-read from memory (L2-resident) wherever it is needed: laundering the pointer keeps the compiler
+        // from hoisting the N loads out of the iteration loop into 2N registers per lane.
+        const double *Hr = opaque_uniform(Hm);
+        double hu = 0.0;
+#pragma unroll 10
+        for (int j = 0; j < N; j++) hu = fma(valid ? Hr[j * N + lane] : 0.0, bcast(U, j), hu);
+        const double vd = dt * incl_prefix(U, lane);
+        const double lamd = validd ? (lpd - lmd) : 0.0;
+        double rd = hu + g + (lpu - lmu) + dt * incl_suffix(lamd, lane);
+        if (!valid) rd = 0.0;
+        const double rppu = valid ? U + tpu - umax : 0.0, rpmu = valid ? -U + tmu - umax : 0.0;
+        const double rppd = validd ? vd + tpd - up_d : 0.0, rpmd = validd ? -vd + tmd + lo_d : 0.0;
+        mu = wave_sum(tpu * lpu + tmu * lmu + tpd * lpd + tmd * lmd) * inv_nc;
+        const double resd = wave_max(fabs(rd));
+        const double resp = wave_max(fmax(fmax(fabs(rppu), fabs(rpmu)), fmax(fabs(rppd), fabs(rpmd))));
+        res = fmax(resd / gscale, resp);
+        // stop at the tolerances, or once the residual has reached the arithmetic's floor and stopped improving
+        if (mu <= prm.tol_mu && (res <= prm.tol_res || res >= 0.5 * res_prev)) break;
+        if (iters >= prm.max_iter) { status = 2; break; }
+        res_prev = res;
+        // Newton matrix  K = H + diag(Du) + dt^2 * Sfx[max(i,j)],  Sfx = suffix sums of Dd
+        const double Du = lpu / tpu + lmu / tmu;
+        const double Dd = validd ? lpd / tpd + lmd / tmd : 0.0;
+        const double sfx = incl_suffix(Dd, lane);
+        const double *Hk = opaque_uniform(Hm);
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const double sj = bcast(sfx, j);
+            double kij = valid ? Hk[j * N + lane] : 0.0;
+            kij = fma(dt2, (j > lane) ? sj : sfx, kij);
+            if (j == lane) kij += Du;
+            nt.row[j] = kij;
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
+        }
+        nt.factor(lane);
+        double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
+        double sigmu = 0.0, alpha = 1.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            double rcpu = tpu * lpu, rcmu = tmu * lmu, rcpd = tpd * lpd, rcmd = tmd * lmd;
+            if (pass) {
+                rcpu += dtpu * dlpu - sigmu; rcmu += dtmu * dlmu - sigmu;
+                rcpd += dtpd * dlpd - sigmu; rcmd += dtmd * dlmd - sigmu;
+            }
+            const double wu = (lpu * rppu - rcpu) / tpu - (lmu * rpmu - rcmu) / tmu;
+            const double wd = validd ? (lpd * rppd - rcpd) / tpd - (lmd * rpmd - rcmd) / tmd : 0.0;
+            double rhs = -rd - wu - dt * incl_suffix(wd, lane);
+            if (!valid) rhs = 0.0;
+            dU = nt.solve(rhs, lane);
+            if (!valid) dU = 0.0;
+            const double dvd = dt * incl_prefix(dU, lane);
+            dtpu = -rppu - dU; dtmu = -rpmu + dU;
+            dlpu = -(rcpu + lpu * dtpu) / tpu; dlmu = -(rcmu + lmu * dtmu) / tmu;
+            dtpd = -rppd - dvd; dtmd = -rpmd + dvd;
+            dlpd = -(rcpd + lpd * dtpd) / tpd; dlmd = -(rcmd + lmd * dtmd) / tmd;
+            if (!valid) { dtpu = 0; dtmu = 0; dlpu = 0; dlmu = 0; }
+            if (!validd) { dtpd = 0; dtmd = 0; dlpd = 0; dlmd = 0; }
+            double al = 1.0;
+            if (dtpu < 0) al = fmin(al, -tpu / dtpu);
+            if (dtmu < 0) al = fmin(al, -tmu / dtmu);
+            if (dlpu < 0) al = fmin(al, -lpu / dlpu);
+            if (dlmu < 0) al = fmin(al, -lmu / dlmu);
+            if (dtpd < 0) al = fmin(al, -tpd / dtpd);
+            if (dtmd < 0) al = fmin(al, -tmd / dtmd);
+            if (dlpd < 0) al = fmin(al, -lpd / dlpd);
+            if (dlmd < 0) al = fmin(al, -lmd / dlmd);
+            alpha = wave_min(al);
+            if (pass == 0) {
+                const double mua = wave_sum((tpu + alpha * dtpu) * (lpu + alpha * dlpu) +
+                                            (tmu + alpha * dtmu) * (lmu + alpha * dlmu) +
+                                            (tpd + alpha * dtpd) * (lpd + alpha * dlpd) +
+                                            (tmd + alpha * dtmd) * (lmd + alpha * dlmd)) * inv_nc;
+                const double sg = mua / mu;
+                sigmu = sg * sg * sg * mu;
+            }
+        }
+        alpha *= 0.995;
+        U = fma(alpha, dU, U);
+        tpu = fma(alpha, dtpu, tpu); tmu = fma(alpha, dtmu, tmu);
+        lpu = fma(alpha, dlpu, lpu); lmu = fma(alpha, dlmu, lmu);
+        tpd = fma(alpha, dtpd, tpd); tmd = fma(alpha, dtmd, tmd);
+        lpd = fma(alpha, dlpd, lpd); lmd = fma(alpha, dlmd, lmd);
+        iters++;
+    }
+    IpmResult out = {U, mu, res, iters, status};
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W]
+template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W; }
+// fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
+constexpr int FIXED_WPB = 4;
+
+template <int N, bool GENERAL>
+__global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2) void k_mpc(const DevCfg cfg,
+                                                                                          const SolveArgs a)
+{
+    constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps scenario addressing scalar
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * WPB + wave;
     const bool valid = lane < N;        // lane owns a decision variable
     const bool validd = lane < N - 1;   // lane owns the bound on delta_{lane+1}
 
-    __shared__ double s_ref[(N + 1) * 3];
-    __shared__ double s_p[N + 1];
-    __shared__ double s_stage[N * STAGE_W];
-    __shared__ double s_wv[6 * N];
+    extern __shared__ double lds[];
+    // GENERAL: [wave area][s_wv 6N][We 36]      fixed: [Kref ncomp*N*N][Kx 5N][wave areas x4]
+    const int ncomp = __popc(a.sh_mask & 7);
+    double *s_K = lds;
+    double *s_Kx = lds + (GENERAL ? 0 : ncomp * N * N);
+    double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_lds_doubles<N>();
+    double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
+    double *s_wv = GENERAL ? wbase + wave_lds_doubles<N>() : nullptr;
+    double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
+    if (GENERAL) {
+        if (lane < 36) s_We[lane] = cfg.We[lane];
+    } else {
+        int ci = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (a.sh_mask & (1 << c)) {
+                for (int i = threadIdx.x; i < N * N; i += WPB * WAVE) s_K[ci * N * N + i] = a.sh_Kref[(size_t)c * N * N + i];
+                ci++;
+            }
+        }
+        for (int i = threadIdx.x; i < 5 * N; i += WPB * WAVE) s_Kx[i] = a.sh_Kx[i];
+        __syncthreads();                 // the only workgroup-wide barrier: from here on the waves are independent
+    }
+    if (s >= a.B) return;
 
     ModelParams mp;
     if (a.mp_scen) {
@@ -89,344 +393,302 @@ __global__ __launch_bounds__(WAVE) void k_mpc(const DevCfg cfg, const SolveArgs 
     } else
         mp = {cfg.mp[0], cfg.mp[1], cfg.mp[2], cfg.mp[3], cfg.mp[4], cfg.mp[5]};
     const double dt = cfg.dt;
+    const double umax = cfg.max_rate, dmax = cfg.max_steering;
+    const double f35 = dt * (-mp.Cf / mp.m), f45 = dt * (-mp.lf * mp.Cf / mp.Iz);
 
-    // ---------------------------------------------------------------- 1. initial state and references
-    double xh3, xh4, xh5;               // controller start [0,0,0,vy,r,delta] (LMPC2.py:298)
-    double plant[8];
-    double dhat = 0.0;
+    // closed-loop state lives in registers across the steps of one launch
+    double plant[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double prevp = 0.0, tvel = 0.0;
     int lapv = 0;
-    if (a.mode == MODE_SOLVE) {
-        const double *x0 = a.x0 + 7 * (size_t)s;
-        xh3 = x0[4]; xh4 = x0[5]; xh5 = x0[6];
-        if (a.d_hat) dhat = a.d_hat[s];
-        for (int k = lane; k <= N; k += WAVE) {
-            const double *w = a.wp + ((size_t)s * (N + 1) + k) * 4;
-            s_ref[k * 3 + 0] = w[0]; s_ref[k * 3 + 1] = w[1]; s_ref[k * 3 + 2] = w[3];   // LMPC2.py:290-294
-            s_p[k] = a.p[(size_t)s * (N + 1) + k];
-        }
-    } else {
+    if (a.mode != MODE_SOLVE) {
 #pragma unroll
         for (int i = 0; i < 8; i++) plant[i] = a.state[8 * (size_t)s + i];
-        xh3 = plant[5]; xh4 = plant[6]; xh5 = plant[7];
-        const double heading = atan2(plant[3], plant[2]);              // skidpad_simulator.py:104
-        const double v = a.target_vel[s];
-        double p0;
-        if (a.mode == MODE_SKIDPAD) {
-            lapv = a.lap[s];
-            int lp = lapv;
-            p0 = sk_pos2progress(plant[0], plant[1], lp);
-            if (a.prev_progress[s] > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(plant[0], plant[1], lp); }
-        } else
-            p0 = plant[0];                                             // step_planning.py:83-86
-        const double ch = cos(heading), sh = sin(heading);
-        for (int k = lane; k <= N; k += WAVE) {
-            double o[4];
-            const double q = waypoint_progress(p0, v, dt, k);
-            if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
-            else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }   // step_planning.py:63-80
-            to_car_frame(o, plant[0], plant[1], ch, sh);
-            s_ref[k * 3 + 0] = o[0]; s_ref[k * 3 + 1] = o[1]; s_ref[k * 3 + 2] = o[3];
-            s_p[k] = v;
-            if (a.wp_out) {
-                double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
-                w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
-            }
-        }
-        if (lane == 0) a.prev_progress[s] = p0;
+        tvel = a.target_vel[s];
+        if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
     }
-    __syncthreads();
+    const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
+    int iters_tot = 0, status_max = 0, nconstr = 0;
+    double mu = 0.0, res = 0.0, u0 = 0.0;
 
-    // ---------------------------------------------------------------- 2. per-stage model (lane k -> stage k)
-    const double b1 = -mp.Cf / mp.m, b2 = -mp.lf * mp.Cf / mp.Iz;
-    const double f35 = dt * b1, f45 = dt * b2;
-    const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;    // OFLMPC2.py:145
-    if (valid) {
-        const double vx = s_p[lane];
-        double a11, a12, a21, a22;
-        lat_coeffs(mp, vx, cfg.eps, a11, a12, a21, a22);
-        StageRow r;
-        r.f33 = 1.0 + dt * a11; r.f34 = dt * a12; r.f43 = dt * a21; r.f44 = 1.0 + dt * a22;
-        if (cfg.kind == MPC_KIND_LPV) {
-            // x+ = x + dt (J(xb)(x - xb) + B (u - ub) + f(xb, vx, ub)), LPVMPC.py:125-171.  Linearisation
-            // point per LPVMPC.py:260-297: "reference" takes ref_points[i,3], a column that is always 0,
-            // as heading; "prev_iter" takes the previous solution shifted by one stage.
-            const double *lx = a.lin_x + (size_t)s * 6 * (N + 1);
-            const double psib = cfg.lpv_lin_prev ? lx[2 * (N + 1) + lane + 1] : 0.0;
-            const double vyb = lx[3 * (N + 1) + lane + 1];
-            const double sn = sin(psib), co = cos(psib);
-            const double J02 = -vx * sn - vyb * co, J03 = -sn, J12 = vx * co - vyb * sn, J13 = co;
-            r.e02 = dt * J02; r.e03 = dt * J03; r.e12 = dt * J12; r.e13 = dt * J13;
-            r.c0 = dt * ((vx * co - vyb * sn) - (J02 * psib + J03 * vyb));
-            r.c1 = dt * ((vx * sn + vyb * co) - (J12 * psib + J13 * vyb));
-        } else {
-            r.e02 = 0.0; r.e03 = 0.0; r.e12 = dt * vx; r.e13 = dt;      // LMPC2.py:127-129
-            r.c0 = dt * vx; r.c1 = 0.0;
-        }
-        double *st = &s_stage[lane * STAGE_W];
-        st[0] = r.e02; st[1] = r.e03; st[2] = r.e12; st[3] = r.e13; st[4] = r.f33; st[5] = r.f34; st[6] = r.f43;
-        st[7] = r.f44; st[8] = r.c0; st[9] = r.c1;
-    }
-    __syncthreads();
-
-    // ---------------------------------------------------------------- 3. condense
-    double wq[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];   // acados scales stage costs by the time step
-    const double wr = dt * cfg.w[6];
-    Newton<N> nt;
-    double g = 0.0;
-    {
-        double *Hrow = nt.row;
-#pragma unroll
-        for (int i = 0; i < N; i++) Hrow[i] = 0.0;
-        double v[6] = {0, 0, 0, 0, 0, 0};
-        double xf[6] = {0, 0, 0, xh3, xh4, xh5};
 #pragma unroll 1
-        for (int k = 1; k <= N; k++) {
-            const double *st = &s_stage[(k - 1) * STAGE_W];
-            const double e02 = st[0], e03 = st[1], e12 = st[2], e13 = st[3], f33 = st[4], f34 = st[5], f43 = st[6],
-                         f44 = st[7], c0 = st[8], c1 = st[9];
-            {   // free response x_k = A_{k-1} x_{k-1} + c_{k-1}
-                const double n0 = xf[0] + e02 * xf[2] + e03 * xf[3] + c0;
-                const double n1 = xf[1] + e12 * xf[2] + e13 * xf[3] + c1;
-                const double n2 = xf[2] + dt * xf[4];
-                const double n3 = f33 * xf[3] + f34 * xf[4] + f35 * xf[5] + c3;
-                const double n4 = f43 * xf[3] + f44 * xf[4] + f45 * xf[5];
-                xf[0] = n0; xf[1] = n1; xf[2] = n2; xf[3] = n3; xf[4] = n4;
+    for (int t = 0; t < nsteps; t++) {
+        // ------------------------------------------------------------ 1. initial state and references
+        double xh3, xh4, xh5;               // controller start [0,0,0,vy,r,delta] (LMPC2.py:298)
+        double dhat = 0.0;
+        if (a.mode == MODE_SOLVE) {
+            const double *x0 = a.x0 + 7 * (size_t)s;
+            xh3 = x0[4]; xh4 = x0[5]; xh5 = x0[6];
+            if (a.d_hat) dhat = a.d_hat[s];
+            for (int k = lane; k <= N; k += WAVE) {
+                const double *w = a.wp + ((size_t)s * (N + 1) + k) * 4;
+                s_ref[k] = w[0]; s_ref[(N + 1) + k] = w[1]; s_ref[2 * (N + 1) + k] = w[3];   // LMPC2.py:290-294
+                s_p[k] = a.p[(size_t)s * (N + 1) + k];
             }
-            {   // column `lane` of the prediction matrix at stage k
-                const double n0 = v[0] + e02 * v[2] + e03 * v[3];
-                const double n1 = v[1] + e12 * v[2] + e13 * v[3];
-                const double n2 = v[2] + dt * v[4];
-                const double n3 = f33 * v[3] + f34 * v[4] + f35 * v[5];
-                const double n4 = f43 * v[3] + f44 * v[4] + f45 * v[5];
-                v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3; v[4] = n4;
-                if (lane == k - 1) { v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0; v[4] = 0; v[5] = dt; }
+        } else {
+            xh3 = plant[5]; xh4 = plant[6]; xh5 = plant[7];
+            const double heading = atan2(plant[3], plant[2]);              // skidpad_simulator.py:104
+            double p0;
+            if (a.mode == MODE_SKIDPAD) {
+                int lp = lapv;
+                p0 = sk_pos2progress(plant[0], plant[1], lp);
+                if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(plant[0], plant[1], lp); }
+                prevp = p0;                                                // path_planning.py:251
+            } else
+                p0 = plant[0];                                             // step_planning.py:83-86
+            const double ch = cos(heading), sh = sin(heading);
+            for (int k = lane; k <= N; k += WAVE) {
+                double o[4];
+                const double q = waypoint_progress(p0, tvel, dt, k);
+                if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
+                else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }   // step_planning.py:63-80
+                to_car_frame(o, plant[0], plant[1], ch, sh);
+                s_ref[k] = o[0]; s_ref[(N + 1) + k] = o[1]; s_ref[2 * (N + 1) + k] = o[3];
+                s_p[k] = tvel;
+                if (a.wp_out) {
+                    double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
+                    w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+                }
             }
-            double err[6] = {xf[0] - s_ref[k * 3 + 0], xf[1] - s_ref[k * 3 + 1], xf[2] - s_ref[k * 3 + 2], xf[3], xf[4],
-                             xf[5]};
-            double wv[6];
-            if (k < N) {
+        }
+        wave_sync();
+
+        // ------------------------------------------------------------ 2. per-stage model (lane k -> stage k)
+        const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;    // OFLMPC2.py:145
+        const bool need_stage = GENERAL || a.traj_out;
+        if (need_stage && valid)
+            stage_model(cfg, mp, s_p[lane], a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr, N, lane,
+                        &s_stage[lane * STAGE_W]);
+
+        // ------------------------------------------------------------ 3. condense, 4. solve
+        const double up_d = dmax - xh5, lo_d = -dmax - xh5;     // bounds on dt * prefix sum
+        double g = 0.0, U = 0.0;
+        int iters = 0, status = 0, constrained = 0;
+        const double *Hm;
+
+        bool fast = !GENERAL || a.sh_H != nullptr;
+        if (fast) {
+            bool same = true;
+            for (int k = lane; k <= N; k += WAVE) same = same && (s_p[k] == a.sh_vx);
+            fast = __all(same);
+        }
+        wave_sync();
+        if (fast) {
+            // Every stage runs at the cached speed: U_unc = -inv(H) g is affine in (vy, r, delta, d_hat, references)
+            // with coefficient matrices condensed once by k_condense_fixed.
+            Hm = a.sh_H;
+            const double *Kx = GENERAL ? a.sh_Kx : s_Kx;
+            double acc = 0.0;
+            if (valid)
+                acc = Kx[lane] * xh3 + Kx[N + lane] * xh4 + Kx[2 * N + lane] * xh5 + Kx[3 * N + lane] + Kx[4 * N + lane] * dhat;
+            int ci = 0;
 #pragma unroll
-                for (int c = 0; c < 6; c++) { wv[c] = wq[c] * v[c]; g = fma(wv[c], err[c], g); }
-            } else {
-                // terminal weight; the LPV terminal reference stays at the constructor's zeros (LPVMPC.py:220-221)
-                if (cfg.kind == MPC_KIND_LPV) { err[0] = xf[0]; err[1] = xf[1]; err[2] = xf[2]; }
+            for (int c = 0; c < 3; c++) {
+                if (a.sh_mask & (1 << c)) {
+                    const double *Kc = GENERAL ? a.sh_Kref + (size_t)c * N * N : s_K + ci * N * N;
+                    const double *rc = s_ref + c * (N + 1) + 1;      // reference of stage kk + 1, read as an LDS broadcast
+                    if (valid) {
+#pragma unroll
+                        for (int kk = 0; kk < N; kk++) {
+                            acc = fma(Kc[kk * N + lane], rc[kk], acc);
+                            if ((kk % 10) == 9) __builtin_amdgcn_sched_barrier(0);   // at most 20 LDS reads in flight
+                        }
+                    }
+                    ci++;
+                }
+            }
+            const double Uu = acc;
+            const double vd = dt * incl_prefix(Uu, lane);
+            bool ok = fabs(Uu) <= umax;
+            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+            if (__all(ok)) U = Uu;
+            else {
+                constrained = 1;
+                double hu = 0.0;                       // g = -H U_unc
+#pragma unroll 10
+                for (int j = 0; j < N; j++) hu = fma(valid ? Hm[j * N + lane] : 0.0, bcast(Uu, j), hu);
+                g = -hu;
+            }
+        } else if (!GENERAL) {
+            Hm = a.sh_H;
+            status = 3;
+        } else {
+            double *Hw = a.Hws + (size_t)s * N * N;
+            Hm = Hw;
+            Newton<N> nt;
+            double wq[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];   // acados scales stage costs by the time step
+            double xf[1][6] = {{0, 0, 0, xh3, xh4, xh5}};
+            const double c01s[1] = {1.0}, c3s[1] = {c3};
+            double gs[1] = {0.0};
+            condense<N, 1>(cfg, lane, s_stage, s_ref, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
+            g = gs[0];
+            const double wr = dt * cfg.w[6];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if (i == lane) nt.row[i] += wr;
+                if (valid) Hw[i * N + lane] = nt.row[i];
+            }
+            if (!valid) g = 0.0;
+            nt.factor(lane);
+            const double Uu = valid ? nt.solve(-g, lane) : 0.0;
+            const double vd = dt * incl_prefix(Uu, lane);
+            bool ok = fabs(Uu) <= umax;
+            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+            if (__all(ok)) U = Uu;
+            else constrained = 1;
+        }
+        if (constrained) {
+            const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
+            const IpmResult r = interior_point<N>(prm, lane, Hm, g, xh5);
+            U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
+        }
+
+        // ------------------------------------------------------------ 5. outputs, prediction, plant
+        if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;
+        u0 = bcast(U, 0);
+        iters_tot += iters; status_max = max(status_max, status); nconstr += constrained;
+        if (a.traj_out || cfg.kind == MPC_KIND_LPV) {
+            // predicted states x_k: lane k keeps stage k, stage N is kept by every lane as `x`
+            double x[6] = {0, 0, 0, xh3, xh4, xh5};
+            double keep[6] = {0, 0, 0, xh3, xh4, xh5};
+#pragma unroll 1
+            for (int k = 0; k < N; k++) {
+                const double *st = &s_stage[k * STAGE_W];
+                const double uk = __shfl(U, k);
+                const double n0 = x[0] + st[0] * x[2] + st[1] * x[3] + st[8];
+                const double n1 = x[1] + st[2] * x[2] + st[3] * x[3] + st[9];
+                const double n2 = x[2] + dt * x[4];
+                const double n3 = st[4] * x[3] + st[5] * x[4] + f35 * x[5] + c3;
+                const double n4 = st[6] * x[3] + st[7] * x[4] + f45 * x[5];
+                const double n5 = x[5] + dt * uk;
+                x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3; x[4] = n4; x[5] = n5;
+                if (lane == k + 1) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) keep[c] = x[c];
+                }
+            }
+            if (a.traj_out) {
+                // 7-column form [x, y, cos(psi), sin(psi), vy, r, delta] (LMPC2.py:337-345)
+                if (valid) {
+                    double *o = a.traj_out + ((size_t)s * (N + 1) + lane) * 7;
+                    o[0] = keep[0]; o[1] = keep[1]; o[2] = cos(keep[2]); o[3] = sin(keep[2]); o[4] = keep[3];
+                    o[5] = keep[4]; o[6] = keep[5];
+                }
+                if (lane == 0) {
+                    double *o = a.traj_out + ((size_t)s * (N + 1) + N) * 7;
+                    o[0] = x[0]; o[1] = x[1]; o[2] = cos(x[2]); o[3] = sin(x[2]); o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
+                }
+            }
+            if (cfg.kind == MPC_KIND_LPV) {
+                // prev_x <- solver states (6 x (N+1)), prev_u <- inputs (LPVMPC.py:313-327)
+                double *lx = a.lin_x + (size_t)s * 6 * (N + 1);
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int d = 0; d < 6; d++) t = fma(cfg.We[c * 6 + d], v[d], t);
-                    wv[c] = t;
-                    g = fma(t, err[c], g);
+                    if (valid) lx[c * (N + 1) + lane] = keep[c];
+                    if (lane == 0) lx[c * (N + 1) + N] = x[c];
                 }
+                if (valid) a.lin_u[(size_t)s * N + lane] = U;
             }
-            if (valid) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) s_wv[c * N + lane] = wv[c];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                if (k == N || wq[c] != 0.0) {
-                    const double vc = v[c];
-#pragma unroll
-                    for (int i = 0; i < N; i++) Hrow[i] = fma(s_wv[c * N + i], vc, Hrow[i]);
-                }
-            }
-            __syncthreads();
         }
-        double *Hg = a.Hws + (size_t)s * N * N;
+        if (a.mode != MODE_SOLVE) {
+            const double oldx = plant[0];
+            plant_rk4<8>(plant, u0, dt, mp);                                // skidpad_simulator.py:128
+            if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
+            if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
+            if (a.x_hist && lane < 8) {
+                double val = plant[0];
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            if (i == lane) Hrow[i] += wr;
-            if (valid) Hg[i * N + lane] = Hrow[i];
+                for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
+                a.x_hist[((size_t)t * a.B + s) * 8 + lane] = val;
+            }
         }
-    }
-    if (!valid) g = 0.0;
+        wave_sync();
+    }   // steps of this launch
 
-    // ---------------------------------------------------------------- 4. solve
-    const double umax = cfg.max_rate, dmax = cfg.max_steering;
-    const double up_d = dmax - xh5, lo_d = -dmax - xh5;     // bounds on dt * prefix sum
-    const double dt2 = dt * dt;
-    const double *Hg = a.Hws + (size_t)s * N * N;
-    double U = 0.0;
-    int iters = 0, status = 0, constrained = 0;
-    double mu = 0.0, res = 0.0;
-
-    // unconstrained minimiser: H is already in nt.row
-    nt.factor(lane);
-    {
-        const double Uu = valid ? nt.solve(-g, lane) : 0.0;
-        const double vd = dt * incl_prefix(Uu, lane);
-        bool ok = fabs(Uu) <= umax;
-        if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
-        if (__all(ok)) U = Uu;
-        else constrained = 1;
-    }
-    if (constrained) {
-        // Mehrotra predictor-corrector on  G U + t = h,  G = [A; -A], A = [I; dt * prefix-sum]
-        const double gscale = fmax(1.0, wave_max(fabs(g)));
-        double tpu, tmu, lpu = 1.0, lmu = 1.0, tpd, tmd, lpd = 1.0, lmd = 1.0;
-        tpu = fmax(umax - U, 0.1 * umax); tmu = fmax(U + umax, 0.1 * umax);
-        tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax);
-        if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
-        if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
-        const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
-        double res_prev = 1e300;
-#pragma unroll 1
-        for (;;) {
-            // residuals
-            double hu = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; j++) hu = fma(valid ? Hg[j * N + lane] : 0.0, bcast(U, j), hu);
-            const double vd = dt * incl_prefix(U, lane);
-            const double lamd = validd ? (lpd - lmd) : 0.0;
-            double rd = hu + g + (lpu - lmu) + dt * incl_suffix(lamd, lane);
-            if (!valid) rd = 0.0;
-            const double rppu = valid ? U + tpu - umax : 0.0, rpmu = valid ? -U + tmu - umax : 0.0;
-            const double rppd = validd ? vd + tpd - up_d : 0.0, rpmd = validd ? -vd + tmd + lo_d : 0.0;
-            mu = wave_sum(tpu * lpu + tmu * lmu + tpd * lpd + tmd * lmd) * inv_nc;
-            const double resd = wave_max(fabs(rd));
-            const double resp = wave_max(fmax(fmax(fabs(rppu), fabs(rpmu)), fmax(fabs(rppd), fabs(rpmd))));
-            res = fmax(resd / gscale, resp);
-            if (mu <= cfg.tol_mu && (res <= cfg.tol_res || res >= 0.5 * res_prev)) break;
-            if (iters >= cfg.max_iter) { status = 2; break; }
-            res_prev = res;
-            // Newton matrix  K = H + diag(Du) + dt^2 * Sfx[max(i,j)],  Sfx = suffix sums of Dd
-            const double Du = lpu / tpu + lmu / tmu;
-            const double Dd = validd ? lpd / tpd + lmd / tmd : 0.0;
-            const double sfx = incl_suffix(Dd, lane);
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const double sj = bcast(sfx, j);
-                double kij = valid ? Hg[j * N + lane] : 0.0;
-                kij = fma(dt2, (j > lane) ? sj : sfx, kij);
-                if (j == lane) kij += Du;
-                nt.row[j] = kij;
-            }
-            nt.factor(lane);
-            double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
-            double sigmu = 0.0, alpha = 1.0;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; pass++) {
-                double rcpu = tpu * lpu, rcmu = tmu * lmu, rcpd = tpd * lpd, rcmd = tmd * lmd;
-                if (pass) {
-                    rcpu += dtpu * dlpu - sigmu; rcmu += dtmu * dlmu - sigmu;
-                    rcpd += dtpd * dlpd - sigmu; rcmd += dtmd * dlmd - sigmu;
-                }
-                const double wu = (lpu * rppu - rcpu) / tpu - (lmu * rpmu - rcmu) / tmu;
-                const double wd = validd ? (lpd * rppd - rcpd) / tpd - (lmd * rpmd - rcmd) / tmd : 0.0;
-                double rhs = -rd - wu - dt * incl_suffix(wd, lane);
-                if (!valid) rhs = 0.0;
-                dU = nt.solve(rhs, lane);
-                if (!valid) dU = 0.0;
-                const double dvd = dt * incl_prefix(dU, lane);
-                dtpu = -rppu - dU; dtmu = -rpmu + dU;
-                dlpu = -(rcpu + lpu * dtpu) / tpu; dlmu = -(rcmu + lmu * dtmu) / tmu;
-                dtpd = -rppd - dvd; dtmd = -rpmd + dvd;
-                dlpd = -(rcpd + lpd * dtpd) / tpd; dlmd = -(rcmd + lmd * dtmd) / tmd;
-                if (!valid) { dtpu = 0; dtmu = 0; dlpu = 0; dlmu = 0; }
-                if (!validd) { dtpd = 0; dtmd = 0; dlpd = 0; dlmd = 0; }
-                double al = 1.0;
-                if (dtpu < 0) al = fmin(al, -tpu / dtpu);
-                if (dtmu < 0) al = fmin(al, -tmu / dtmu);
-                if (dlpu < 0) al = fmin(al, -lpu / dlpu);
-                if (dlmu < 0) al = fmin(al, -lmu / dlmu);
-                if (dtpd < 0) al = fmin(al, -tpd / dtpd);
-                if (dtmd < 0) al = fmin(al, -tmd / dtmd);
-                if (dlpd < 0) al = fmin(al, -lpd / dlpd);
-                if (dlmd < 0) al = fmin(al, -lmd / dlmd);
-                alpha = wave_min(al);
-                if (pass == 0) {
-                    const double mua = wave_sum((tpu + alpha * dtpu) * (lpu + alpha * dlpu) +
-                                                (tmu + alpha * dtmu) * (lmu + alpha * dlmu) +
-                                                (tpd + alpha * dtpd) * (lpd + alpha * dlpd) +
-                                                (tmd + alpha * dtmd) * (lmd + alpha * dlmd)) * inv_nc;
-                    const double sg = mua / mu;
-                    sigmu = sg * sg * sg * mu;
-                }
-            }
-            alpha *= 0.995;
-            U = fma(alpha, dU, U);
-            tpu = fma(alpha, dtpu, tpu); tmu = fma(alpha, dtmu, tmu);
-            lpu = fma(alpha, dlpu, lpu); lmu = fma(alpha, dlmu, lmu);
-            tpd = fma(alpha, dtpd, tpd); tmd = fma(alpha, dtmd, tmd);
-            lpd = fma(alpha, dlpd, lpd); lmd = fma(alpha, dlmd, lmd);
-            iters++;
-        }
-    }
-
-    // ---------------------------------------------------------------- 5. outputs, prediction, plant
-    if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;
-    const double u0 = bcast(U, 0);
-    if (lane == 0) {
-        if (a.u0_out) a.u0_out[s] = u0;
-        if (a.status_out) a.status_out[s] = status;
-        if (a.iters_out) a.iters_out[s] = iters;
-        if (a.stat_out) {
-            double *so = a.stat_out + 4 * (size_t)s;
-            so[0] = mu; so[1] = res; so[2] = (double)constrained; so[3] = fabs(u0);
-        }
-    }
-    if (a.traj_out || cfg.kind == MPC_KIND_LPV) {
-        // predicted states x_k (lane k keeps stage k; stage N falls to lane N % 64 on a second sweep)
-        double x[6] = {0, 0, 0, xh3, xh4, xh5};
-        double keep[6] = {0, 0, 0, xh3, xh4, xh5};
-        double last[6];
-#pragma unroll 1
-        for (int k = 0; k < N; k++) {
-            const double *st = &s_stage[k * STAGE_W];
-            const double uk = __shfl(U, k);
-            const double n0 = x[0] + st[0] * x[2] + st[1] * x[3] + st[8];
-            const double n1 = x[1] + st[2] * x[2] + st[3] * x[3] + st[9];
-            const double n2 = x[2] + dt * x[4];
-            const double n3 = st[4] * x[3] + st[5] * x[4] + f35 * x[5] + c3;
-            const double n4 = st[6] * x[3] + st[7] * x[4] + f45 * x[5];
-            const double n5 = x[5] + dt * uk;
-            x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3; x[4] = n4; x[5] = n5;
-            if (lane == k + 1) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) keep[c] = x[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) last[c] = x[c];
-        if (a.traj_out) {
-            // 7-column form [x, y, cos(psi), sin(psi), vy, r, delta] (LMPC2.py:337-345)
-            if (lane <= N && lane < WAVE) {
-                const double *q = (lane == N) ? last : keep;
-                double *o = a.traj_out + ((size_t)s * (N + 1) + lane) * 7;
-                o[0] = q[0]; o[1] = q[1]; o[2] = cos(q[2]); o[3] = sin(q[2]); o[4] = q[3]; o[5] = q[4]; o[6] = q[5];
-            }
-            if (N == WAVE && lane == 0) {
-                double *o = a.traj_out + ((size_t)s * (N + 1) + N) * 7;
-                o[0] = last[0]; o[1] = last[1]; o[2] = cos(last[2]); o[3] = sin(last[2]); o[4] = last[3];
-                o[5] = last[4]; o[6] = last[5];
-            }
-        }
-        if (cfg.kind == MPC_KIND_LPV) {
-            // prev_x <- solver states (6 x (N+1)), prev_u <- inputs (LPVMPC.py:313-327)
-            double *lx = a.lin_x + (size_t)s * 6 * (N + 1);
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                if (valid) lx[c * (N + 1) + lane] = keep[c];
-                if (lane == 0) lx[c * (N + 1) + N] = last[c];
-            }
-            if (valid) a.lin_u[(size_t)s * N + lane] = U;
-        }
-    }
     if (a.mode != MODE_SOLVE) {
-        const double oldx = plant[0];
-        plant_rk4<8>(plant, u0, dt, mp);                                // skidpad_simulator.py:128
         if (lane < 8) {
             double val = plant[0];
 #pragma unroll
             for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
             a.state[8 * (size_t)s + lane] = val;
         }
-        if (a.mode == MODE_SKIDPAD && lane == 0 && plant[0] > SK_CENTER && oldx <= SK_CENTER)
-            a.lap[s] = lapv + 1;                                        // skidpad_simulator.py:91-93
+        if (a.mode == MODE_SKIDPAD && lane == 0) { a.lap[s] = lapv; a.prev_progress[s] = prevp; }
+    }
+    if (lane == 0) {
+        if (a.u0_out) a.u0_out[s] = u0;
+        if (a.status_out) a.status_out[s] = status_max;
+        if (a.iters_out) a.iters_out[s] = iters_tot;
+        if (a.stat_out) {
+            double *so = a.stat_out + 4 * (size_t)s;
+            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-model cache: condense once for "every stage at speed vx", factor H and apply inv(H) to each way the
+// gradient depends on the step's data.  One wavefront; a set-up cost of about 3N+5 triangular solve pairs.
+template <int N>
+__global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, double vx, double *H, double *Kref, double *Kx)
+{
+    const int lane = threadIdx.x;
+    const bool valid = lane < N;
+    __shared__ double s_stage[N * STAGE_W];
+    __shared__ double s_wv[6 * N];
+    __shared__ double s_We[36];
+    if (lane < 36) s_We[lane] = cfg.We[lane];
+    const ModelParams mp = {cfg.mp[0], cfg.mp[1], cfg.mp[2], cfg.mp[3], cfg.mp[4], cfg.mp[5]};
+    const double dt = cfg.dt;
+    if (valid) stage_model(cfg, mp, vx, nullptr, N, lane, &s_stage[lane * STAGE_W]);
+    wave_sync();
+    double wq[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];
+    const double f35 = dt * (-mp.Cf / mp.m), f45 = dt * (-mp.lf * mp.Cf / mp.Iz);
+    // free responses: unit vy, unit r, unit delta, the model's constant term, unit d_hat
+    double xf[5][6] = {{0, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 1, 0}, {0, 0, 0, 0, 0, 1}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    const double c01s[5] = {0, 0, 0, 1, 0}, c3s[5] = {0, 0, 0, 0, dt};
+    double g[5] = {0, 0, 0, 0, 0};
+    Newton<N> nt;
+    condense<N, 5>(cfg, lane, s_stage, nullptr, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, g, Kref);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (i == lane) nt.row[i] += dt * cfg.w[6];
+        if (valid) H[i * N + lane] = nt.row[i];
+    }
+    nt.factor(lane);
+#pragma unroll 1
+    for (int f = 0; f < 5; f++) {
+        double gf = g[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++) gf = (f == q) ? g[q] : gf;
+        const double x = nt.solve(valid ? -gf : 0.0, lane);
+        if (valid) Kx[f * N + lane] = x;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ck = 0; ck < 3 * N; ck++) {
+        const double rhs = valid ? Kref[(size_t)ck * N + lane] : 0.0;
+        const double x = nt.solve(rhs, lane);
+        if (valid) Kref[(size_t)ck * N + lane] = x;
+    }
+}
+
+template <int N>
+static hipError_t launch_fixed_n(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_condense_fixed<N>, dim3(1), dim3(WAVE), 0, st, cfg, vx, H, Kref, Kx);
+    return hipGetLastError();
+}
+
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st)
+{
+    switch (cfg.N) {
+#define MPC_CASE(n) case n: return launch_fixed_n<n>(cfg, vx, H, Kref, Kx, st);
+        MPC_HORIZONS(MPC_CASE)
+#undef MPC_CASE
+    default: return hipErrorInvalidValue;
     }
 }
 
@@ -434,7 +696,21 @@ __global__ __launch_bounds__(WAVE) void k_mpc(const DevCfg cfg, const SolveArgs 
 template <int N>
 static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mpc<N>, dim3(a.B), dim3(WAVE), 0, st, cfg, a);
+    if (a.sh_H && a.sh_exclusive) {
+        const int ncomp = __builtin_popcount(a.sh_mask & 7);
+        const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_lds_doubles<N>());
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc<N, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_mpc<N, false>), dim3((a.B + FIXED_WPB - 1) / FIXED_WPB), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
+    } else {
+        const size_t lds = sizeof(double) * (size_t)(wave_lds_doubles<N>() + 6 * N + 36);
+        hipLaunchKernelGGL((k_mpc<N, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+    }
     return hipGetLastError();
 }
 
