@@ -76,7 +76,8 @@ class _CondensedMpc:
     n_outputs = 5
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
-                 batch: int = 1, tol_mu: float = 1e-13, tol_res: float = 1e-12, max_iter: int = 60):
+                 batch: int = 1, tol_mu: float = 1e-13, tol_res: float = 1e-12, max_iter: int = 60,
+                 _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
@@ -96,10 +97,14 @@ class _CondensedMpc:
         self.u_lin_point = np.zeros(1)
         self.p_lin_point = np.array([15.0])
         self.W, self.W_e = self._cost_matrices()
-        self.device = _dev.require_gpu(device)
         self.batch = int(batch)
         self._tol = (tol_mu, tol_res, max_iter)
-        self.solver = SolverHandle(self._make_config())
+        if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
+            self.device = None
+            self.solver = None
+        else:
+            self.device = _dev.require_gpu(device)
+            self.solver = SolverHandle(self._make_config())
         self.metrics = {"runtime": []}
         self._bufs = {}
 
@@ -142,7 +147,7 @@ class _CondensedMpc:
         cfg.kind = _lib.KIND[self.kind]
         cfg.N = self.N
         cfg.B = self.batch
-        cfg.device = self.device.index
+        cfg.device = self.device.index if self.device is not None else 0
         cfg.dt = self.dt
         cfg.mp[:] = list(self.model_params())
         cfg.max_steering = self.max_steering

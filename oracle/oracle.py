@@ -21,7 +21,7 @@ import yaml
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 KIND = {"L": 0, "OFL": 1, "LPV": 2}
-CFG_LEN = 55
+CFG_LEN = 56
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -196,7 +196,8 @@ def dare_terminal(mp, dt, W):
     return P, K, A, B
 
 
-def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Oracle | None = None) -> np.ndarray:
+def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Oracle | None = None,
+             lin_mode: str = "reference") -> np.ndarray:
     params = params or load_params(kind)
     mp = model_params(params, orc)
     dt = Tf / N
@@ -215,6 +216,7 @@ def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Orac
     cfg[0] = KIND[kind]; cfg[1] = N; cfg[2] = dt; cfg[3:9] = mp
     cfg[9] = params["model"]["max_steering_angle"]; cfg[10] = params["model"]["max_steering_rate"]
     cfg[11:18] = np.diag(W); cfg[18:54] = We.reshape(-1); cfg[54] = 1e-3
+    cfg[55] = 1.0 if lin_mode == "prev_iter" else 0.0
     return cfg
 
 

@@ -1,0 +1,112 @@
+"""CPU-side checks: the C-ABI library builds for gfx950, loads, and exports every symbol include/mpc_amd.h declares
+(no compute call is made without a GPU); the host set-up arithmetic agrees with the checker; the product fails
+loudly without a GPU and never touches the checker."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from mpc_amd import _build
+    return _build.build_library()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mpc_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    names = _declared()
+    assert len(names) >= 17
+    lib = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/mpc_amd.h but not exported"
+
+
+def test_ctypes_binding_covers_the_header(lib_path):
+    from mpc_amd import _lib
+    assert sorted(_lib.EXPORTS) == _declared()
+    _lib.load()                                   # sets argtypes on every symbol; raises if one is missing
+
+
+def test_config_struct_matches_header_layout():
+    from mpc_amd import _lib
+    c = _lib.MpcConfig
+    # ints 4*4, dt 8, mp 48, two bounds 16, w 56, We 288, eps/tol_mu/tol_res 24, two ints 8
+    assert ctypes.sizeof(c) == 16 + 8 + 48 + 16 + 56 + 288 + 24 + 8
+    assert c.dt.offset == 16 and c.w.offset == 16 + 8 + 48 + 16 and c.max_iter.offset == ctypes.sizeof(c) - 8
+
+
+@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("OFL", 50, 1.0), ("LPV", 80, 0.8), ("L", 10, 0.5)])
+def test_host_setup_matches_checker(orc64, kind, N, Tf):
+    from oracle import oracle as O
+    from mpc_amd.controllers import LOcp, LPVOcp, OFLOcp
+    cls = {"L": LOcp, "OFL": OFLOcp, "LPV": LPVOcp}[kind]
+    ctl = cls(N, Tf, _host_only=True)
+    cfg = ctl._make_config()
+    ref = O.make_cfg(kind, N, Tf)
+    assert (cfg.kind, cfg.N) == (int(ref[0]), int(ref[1]))
+    np.testing.assert_allclose(cfg.dt, ref[2], rtol=0, atol=0)
+    np.testing.assert_array_equal(np.array(cfg.mp[:]), ref[3:9])           # tyre stiffness bit-exact with np.interp
+    assert (cfg.max_steering, cfg.max_rate) == (ref[9], ref[10])
+    np.testing.assert_array_equal(np.array(cfg.w[:]), ref[11:18])
+    np.testing.assert_allclose(np.array(cfg.We[:]), ref[18:54], rtol=1e-12, atol=1e-9)
+    if kind != "LPV":
+        assert ctl.P.shape == (5, 5) and ctl.K.shape == (1, 5)
+        assert ctl.A_stability.dtype == np.float32 and ctl.A_stability.shape == (5, 5)
+
+
+def test_terminal_set_known_answer_through_host_model(golden):
+    """terminal_set.m:4-10 of the reference: float32 forward-Euler (A, B) at vx = 15, dt = 0.02."""
+    from mpc_amd.controllers import LOcp
+    ctl = LOcp(50, 1.0, _host_only=True)          # dt = 0.02
+    g = golden["kat_terminal_set"]
+    np.testing.assert_allclose(ctl.A_stability, g["A"], rtol=2e-7, atol=5e-9)
+    np.testing.assert_allclose(ctl.B_stability[:, 0], g["B"], rtol=1e-7, atol=0)   # float32 0.02 vs the printed 0.02
+    assert (ctl.Cf, ctl.Cr) == (18879.96006089543, 24292.066639693276)
+
+
+def test_product_needs_a_gpu_and_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mpc_amd.controllers import LOcp
+    from mpc_amd.continuous_dynamics import Dynamics
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        LOcp(50, 0.5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Dynamics(0.01)
+
+
+def test_product_never_references_the_checker():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "mpc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp")):
+                if re.search(r"\boracle\b", open(os.path.join(d, f), errors="ignore").read()):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_parameter_files_read_like_the_reference(tmp_path, monkeypatch):
+    """parameters_*.yaml is looked up in the working directory first (LMPC2.py:31), then in the package."""
+    import yaml
+    from mpc_amd.controllers import LOcp, read_parameters
+    base = read_parameters("parameters_L.yaml")
+    assert base["controller"]["r"] == 10.0 and base["model"]["m"] == 180
+    mod = yaml.safe_load(yaml.safe_dump(base)); mod["controller"]["r"] = 3.0; mod["controller"]["beta"] = 2
+    (tmp_path / "parameters_L.yaml").write_text(yaml.safe_dump(mod))
+    monkeypatch.chdir(tmp_path)
+    ctl = LOcp(50, 0.5, _host_only=True)
+    assert ctl.W[6, 6] == 3.0
+    ref = LOcp(50, 0.5, _host_only=True, params=base)
+    np.testing.assert_allclose(ctl.W_e[1:6, 1:6], 2 * 0.5 * ctl.P)
+    np.testing.assert_allclose(ctl.P, ref.P)      # the reference's DARE takes R' = W[4,4] = 0, so r does not enter P

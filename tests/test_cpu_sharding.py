@@ -1,0 +1,63 @@
+"""Multi-rank path on CPU: scenario sharding and the statistics all-reduce with the gloo backend, world size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpc_amd.sharding import allreduce_stats, shard_bounds
+    lo, hi = shard_bounds(total, rank, world)
+    owned = np.arange(lo, hi)
+    # per-rank statistics of "its" scenarios: sums (count, sum of ids) and maxima (largest id, rank-dependent value)
+    sums = torch.tensor([float(len(owned)), float(owned.sum())], dtype=torch.float64)
+    maxima = torch.tensor([float(owned.max()), 10.0 * (rank + 1)], dtype=torch.float64)
+    allreduce_stats(sums, maxima)
+    q.put((rank, lo, hi, sums.tolist(), maxima.tolist()))
+    dist.destroy_process_group()
+
+
+def test_shards_cover_and_statistics_reduce_world2():
+    world, total = 2, 4097
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, s0, m0), (r1, lo1, hi1, s1, m1) = out
+    assert (lo0, hi0, lo1, hi1) == (0, 2049, 2049, 4097)            # contiguous, disjoint, complete
+    assert s0 == s1 == [float(total), float(total * (total - 1) // 2)]
+    assert m0 == m1 == [float(total - 1), 20.0]
+
+
+def test_shard_bounds_properties():
+    from mpc_amd.sharding import shard_bounds
+    for total in (0, 1, 7, 4096, 65536, 1048576 + 3):
+        for world in (1, 2, 4, 8):
+            edges = [shard_bounds(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+    # outside a process group the reduction is the identity
+    from mpc_amd.sharding import allreduce_stats
+    a, b = allreduce_stats(torch.ones(3), torch.zeros(2))
+    assert a.tolist() == [1, 1, 1] and b.tolist() == [0, 0]
