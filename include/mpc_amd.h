@@ -103,6 +103,16 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
                         double *u0_out, double *wp_out, double *traj_out, double *U_out, double *u_hist,
                         double *x_hist, int *status_out, int *iters_out);
 
+/* Output-feedback closed loop, nsteps fused steps per launch (StepSimulator.simulate_of, simulator.py:206-281):
+ * step planner and OFL controller on the EKF estimate (d_hat = estimate[9]), 10-state plant with disturbances,
+ * EKF predict (EKF.py:38-43) and update (EKF.py:45-49) on y = H x_true (+ meas_noise[nsteps][B][7] if given).
+ *   state10 [B][10] true plant state, ekf_x [B][10], ekf_P [B][10][10] (all updated); q_diag / r_diag host arrays
+ *   of 10 / 7; u_hist [nsteps][B], x_hist [nsteps][B][10], est_hist [nsteps][B][10] optional. */
+int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, double *state10, double *ekf_x, double *ekf_P,
+                            const double *target_vel, const double *q_diag_host, const double *r_diag_host,
+                            const double *meas_noise, double *u0_out, double *u_hist, double *x_hist, double *est_hist,
+                            int *status_out, int *iters_out);
+
 /* Dynamics.single_track_model / rk4_integraton (continuous_dynamics.py:90-133): x [B][nx], nx = 8 or 10. */
 int mpc_plant_rk4(void *stream, int B, int nx, double dt, const double *mp6_host, double *x, const double *u);
 int mpc_plant_f(void *stream, int B, int nx, const double *mp6_host, const double *x, const double *u, double *xdot);

@@ -34,6 +34,7 @@ _SIGS = {
     "mpc_solve_only": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
     "mpc_closed_loop_step": ([_vp, _vp, C.c_int, C.c_int] + [_vp] * 12, C.c_int),
     "mpc_closed_loop_run": ([_vp, _vp, C.c_int, C.c_int, C.c_int] + [_vp] * 14, C.c_int),
+    "mpc_ofl_closed_loop_run": ([_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, _dp] + [_vp] * 7, C.c_int),
     "mpc_plant_rk4": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _vp, _vp], C.c_int),
     "mpc_plant_f": ([_vp, C.c_int, C.c_int, _dp, _vp, _vp, _vp], C.c_int),
     "mpc_ekf_time_update": ([_vp, C.c_int, C.c_double, _dp, _dp, _vp, _vp, _vp], C.c_int),

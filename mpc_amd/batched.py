@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 from . import _dev, _lib
-from .controllers import LOcp, LPVOcp
+from .controllers import LOcp, LPVOcp, OFLOcp
+from .EKF import P0_DIAG, Q_DIAG
 
 
 class _ClosedLoopBatch:
@@ -92,3 +93,49 @@ class SkidpadBatch(_ClosedLoopBatch):
 
 class StepBatch(_ClosedLoopBatch):
     planner = _lib.PLANNER_STEP
+
+
+class StepOFLBatch:
+    """Batched output-feedback loop (StepSimulator(model="OFL").simulate_of, simulator.py:206-281): B scenarios,
+    each with its own true plant state (10 states incl. disturbances), EKF estimate and covariance, all resident
+    in HBM; one launch advances every scenario by n steps."""
+
+    def __init__(self, N, Tf, true_states, estimates=None, device=None, target_vel=None, fixed_model_cache=True, **ctl_kw):
+        x = np.ascontiguousarray(true_states, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != 10:
+            raise ValueError("true_states must be (B, 10)")
+        self.B = B = x.shape[0]
+        self.N, self.Tf, self.dt = int(N), float(Tf), float(Tf) / int(N)
+        self.ocp = self.MPC_controller = OFLOcp(N, Tf, batch=B, device=device, **ctl_kw)
+        dev = self.device = self.ocp.device
+        self.state = _dev.f64(x, dev)
+        if estimates is None:                       # simulator.py:214-224
+            estimates = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (B, 1))
+        self.estimate = _dev.f64(np.ascontiguousarray(estimates, dtype=np.float64), dev).clone()
+        self.P = _dev.f64(np.tile(np.diag(P0_DIAG), (B, 1, 1)), dev).clone()
+        tv = x[:, 4] if target_vel is None else np.broadcast_to(np.asarray(target_vel, dtype=np.float64), (B,))
+        self.target_vel = _dev.f64(np.ascontiguousarray(tv), dev)
+        if fixed_model_cache and np.all(tv == tv[0]):
+            self.ocp.condense_fixed(float(tv[0]), exclusive=True)
+        self._qd = np.ascontiguousarray(Q_DIAG, dtype=np.float64)
+        self._rd = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])             # R = diag(sigma) (EKF.py:32)
+        self.u0 = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def run(self, n_steps: int, record: bool = False, meas_noise=None):
+        """meas_noise: optional (n_steps, B, 7) additive measurement noise (e.g. sigma * N(0,1) per channel)."""
+        dev = self.device
+        xs = torch.empty((n_steps, self.B, 10), dtype=torch.float64, device=dev) if record else None
+        es = torch.empty((n_steps, self.B, 10), dtype=torch.float64, device=dev) if record else None
+        us = torch.empty((n_steps, self.B), dtype=torch.float64, device=dev) if record else None
+        noise = _dev.f64(meas_noise, dev) if meas_noise is not None else None
+        if noise is not None and tuple(noise.shape) != (n_steps, self.B, 7):
+            raise ValueError("meas_noise must be (n_steps, B, 7)")
+        s = self.ocp.solver
+        rc = s._lib.mpc_ofl_closed_loop_run(
+            s.h, _dev.stream_ptr(dev), self.B, int(n_steps), _dev.ptr(self.state), _dev.ptr(self.estimate),
+            _dev.ptr(self.P), _dev.ptr(self.target_vel), _lib.hptr(self._qd), _lib.hptr(self._rd), _dev.ptr(noise),
+            _dev.ptr(self.u0), _dev.ptr(us), _dev.ptr(xs), _dev.ptr(es), _dev.ptr(self.status), _dev.ptr(self.iters))
+        _lib.check(rc, s.h, "mpc_ofl_closed_loop_run")
+        return (xs, us, es) if record else None

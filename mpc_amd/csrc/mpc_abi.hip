@@ -147,7 +147,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_solve_only: x0, wp, p and U_out are required");
     if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_solve_only: LPV needs lin_x and lin_u");
     mpc::SolveArgs a = {};
-    a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
+    a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.U_out = U_out; a.traj_out = traj_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
@@ -185,10 +185,33 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     if (h->cfg.kind == MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: the OFL loop runs on the estimate; use mpc_solve_only with the EKF entry points");
     mpc::SolveArgs a = {};
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
-    a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist;
+    a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist; a.nx_plant = 8;
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
+    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.stat_out = h->stat;
+    attach_cache(h, a);
+    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
+    return MPC_OK;
+}
+
+int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, double *state10, double *ekf_x, double *ekf_P,
+                            const double *target_vel, const double *q_diag_host, const double *r_diag_host,
+                            const double *meas_noise, double *u0_out, double *u_hist, double *x_hist, double *est_hist,
+                            int *status_out, int *iters_out)
+{
+    if (int rc = check_batch(h, B, "mpc_ofl_closed_loop_run")) return rc;
+    if (h->cfg.kind != MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: handle is not an OFL controller");
+    if (nsteps < 1 || !state10 || !ekf_x || !ekf_P || !target_vel || !q_diag_host || !r_diag_host || !u0_out)
+        return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: missing argument");
+    mpc::SolveArgs a = {};
+    a.mode = mpc::MODE_OFL; a.B = B; a.nsteps = nsteps; a.nx_plant = 10;
+    a.state = state10; a.target_vel = target_vel; a.ekf_x = ekf_x; a.ekf_P = ekf_P; a.meas_noise = meas_noise;
+    for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
+    for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
+    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);

@@ -59,36 +59,11 @@ hipError_t launch_plant_f(hipStream_t st, int B, int nx, const double *mp6, cons
 }
 
 // -------------------------------------------------------------------------------------------- EKF
-// F = I + dt*A of Dynamics.jacobian_forward_euler (continuous_dynamics.py:167-210), including its log(vx)
-// terms, the positive tf22dr and the 1/m side-force column (:151-165), which the estimator depends on.
 __device__ __forceinline__ void ekf_jacobian(const double *x, double dt, const ModelParams &mp, double *F)
 {
 #pragma unroll
-    for (int i = 0; i < 100; i++) F[i] = 0.0;
-    const double lg = log(x[4]);
-    const double cs = mp.Cf + mp.Cr, cd = mp.Cr * mp.lr - mp.Cf * mp.lf, ci = mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr;
-    const double tf11dvx = -cs / mp.m * x[5] * lg;
-    const double tf11dvy = -cs / (mp.m * x[4]);
-    const double tf12dvx = -x[6] + cd / mp.m * lg;
-    const double tf12dr = -x[4] + cd / (mp.m * x[4]);
-    const double tf1dd = -mp.Cf / mp.m;
-    const double tf21dvx = (mp.lr * mp.Cr - mp.lf * mp.Cf) / mp.Iz * x[5] * lg;
-    const double tf21dvy = (mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * x[4]);
-    const double tf22dvx = (ci / mp.Iz * x[6]) * lg;
-    const double tf22dr = ci / (mp.Iz * x[4]);
-    const double tf2dd = -(mp.Cf * mp.lf) / mp.Iz;
-#define FF(r, c) F[(r) * 10 + (c)]
-    FF(0, 2) = dt * x[4]; FF(0, 3) = dt * -x[5]; FF(0, 4) = dt * x[2]; FF(0, 5) = dt * -x[3];
-    FF(1, 2) = dt * x[5]; FF(1, 3) = dt * x[4];  FF(1, 4) = dt * x[3]; FF(1, 5) = dt * x[2];
-    FF(2, 3) = dt * -x[6]; FF(2, 6) = dt * -x[3];
-    FF(3, 2) = dt * x[6];  FF(3, 6) = dt * x[2];
-    FF(5, 4) = dt * (tf11dvx + tf12dvx); FF(5, 5) = dt * tf11dvy; FF(5, 6) = dt * tf12dr; FF(5, 7) = dt * tf1dd;
-    FF(6, 4) = dt * (tf21dvx + tf22dvx); FF(6, 5) = dt * tf21dvy; FF(6, 6) = dt * tf22dr; FF(6, 7) = dt * tf2dd;
-    FF(5, 8) = dt * (-mp.Cf / mp.m); FF(6, 8) = dt * (-(mp.Cf * mp.lf) / mp.Iz);
-    FF(5, 9) = dt * (1.0 / mp.m);
-#undef FF
-#pragma unroll
-    for (int i = 0; i < 10; i++) F[i * 10 + i] += 1.0;
+    for (int i = 0; i < 100; i++) F[i] = (i / 10 == i % 10) ? 1.0 : 0.0;
+    ekf_jacobian_entries(x, dt, mp, F);
 }
 
 __global__ __launch_bounds__(64) void k_ekf_jacobian(int B, double dt, MP6 m, const double *x, double *Fout)

@@ -106,6 +106,36 @@ __device__ __forceinline__ void plant_rk4(double *x, double u, double dt, const 
     for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
 }
 
+// ---------------------------------------------------------------- EKF linearisation
+// Off-diagonal and non-unit entries of F = I + dt*A of Dynamics.jacobian_forward_euler (continuous_dynamics.py:167-210),
+// including its log(vx) terms, the positive tf22dr and the 1/m side-force column (:151-165) the estimator depends on.
+// F (row-major 10x10) must already hold the identity.
+__device__ __forceinline__ void ekf_jacobian_entries(const double *x, double dt, const ModelParams &mp, double *F)
+{
+    const double lg = log(x[4]);
+    const double cs = mp.Cf + mp.Cr, cd = mp.Cr * mp.lr - mp.Cf * mp.lf, ci = mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr;
+    const double tf11dvx = -cs / mp.m * x[5] * lg;
+    const double tf11dvy = -cs / (mp.m * x[4]);
+    const double tf12dvx = -x[6] + cd / mp.m * lg;
+    const double tf12dr = -x[4] + cd / (mp.m * x[4]);
+    const double tf1dd = -mp.Cf / mp.m;
+    const double tf21dvx = (mp.lr * mp.Cr - mp.lf * mp.Cf) / mp.Iz * x[5] * lg;
+    const double tf21dvy = (mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * x[4]);
+    const double tf22dvx = (ci / mp.Iz * x[6]) * lg;
+    const double tf22dr = ci / (mp.Iz * x[4]);
+    const double tf2dd = -(mp.Cf * mp.lf) / mp.Iz;
+#define FF(r, c) F[(r) * 10 + (c)]
+    FF(0, 2) = dt * x[4]; FF(0, 3) = dt * -x[5]; FF(0, 4) = dt * x[2]; FF(0, 5) = dt * -x[3];
+    FF(1, 2) = dt * x[5]; FF(1, 3) = dt * x[4];  FF(1, 4) = dt * x[3]; FF(1, 5) = dt * x[2];
+    FF(2, 3) = dt * -x[6]; FF(2, 6) = dt * -x[3];
+    FF(3, 2) = dt * x[6];  FF(3, 6) = dt * x[2];
+    FF(5, 4) = dt * (tf11dvx + tf12dvx); FF(5, 5) = 1.0 + dt * tf11dvy; FF(5, 6) = dt * tf12dr; FF(5, 7) = dt * tf1dd;
+    FF(6, 4) = dt * (tf21dvx + tf22dvx); FF(6, 5) = dt * tf21dvy; FF(6, 6) = 1.0 + dt * tf22dr; FF(6, 7) = dt * tf2dd;
+    FF(5, 8) = dt * (-mp.Cf / mp.m); FF(6, 8) = dt * (-(mp.Cf * mp.lf) / mp.Iz);
+    FF(5, 9) = dt * (1.0 / mp.m);
+#undef FF
+}
+
 // ---------------------------------------------------------------- planners
 constexpr double SK_R = 9.125, SK_CENTER = 16.75;
 constexpr double PI = 3.14159265358979323846;

@@ -10,7 +10,7 @@
 
 namespace mpc {
 
-enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2 };
+enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2, MODE_OFL = 3 };   // OFL: step planner on the EKF estimate
 
 struct DevCfg {
     int kind, N, lpv_lin_prev, max_iter;
@@ -23,7 +23,11 @@ struct DevCfg {
 struct SolveArgs {
     int mode, B;
     int nsteps;                                           // closed-loop modes: steps advanced by one launch
-    double *u_hist, *x_hist;                              // optional [nsteps][B] inputs / [nsteps][B][8] states
+    double *u_hist, *x_hist;                              // optional [nsteps][B] inputs / [nsteps][B][nx_plant] states
+    int nx_plant;                                         // 8, or 10 with the disturbance states (MODE_OFL)
+    double *ekf_x, *ekf_P, *est_hist;                     // MODE_OFL: estimate [B][10], covariance [B][10][10], [nsteps][B][10]
+    const double *meas_noise;                             // MODE_OFL: optional additive noise [nsteps][B][7]
+    double ekf_q[10], ekf_r[7];                           // MODE_OFL: diag(Q), diag(R)
     const double *x0, *wp, *p, *d_hat;                    // MODE_SOLVE inputs
     double *state; int *lap; double *prev_progress;       // closed-loop state (updated)
     const double *target_vel;

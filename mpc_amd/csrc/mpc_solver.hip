@@ -345,6 +345,106 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-cooperative EKF on LDS-resident data (10 states, 7 measured channels).  Lane e handles covariance entries
+// e and e + 64; uniform scalars are recomputed by every lane.
+constexpr int EKF_LDS = 10 + 100 + 100 + 100 + 7 * 17;   // xe, P, F, T, augmented system
+__device__ __constant__ int c_meas[7] = {0, 1, 2, 3, 4, 6, 7};   // continuous_dynamics.py:35-45
+
+// EKF.py:38-43: x <- x + dt f(x,u) (forward Euler), F at the pre-update estimate, P <- F P F' + Q
+__device__ __forceinline__ void ekf_time_update_wave(int lane, double *xe, double *P, double *F, double *T, double u,
+                                                     double dt, const ModelParams &mp, const double *qd)
+{
+    double x[10], xd[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) x[i] = xe[i];
+    plant_f<10>(x, u, mp, xd);
+    for (int e = lane; e < 100; e += WAVE) F[e] = (e / 10 == e % 10) ? 1.0 : 0.0;
+    wave_sync();
+    if (lane == 0) ekf_jacobian_entries(x, dt, mp, F);
+    wave_sync();
+    for (int e = lane; e < 100; e += WAVE) {
+        const int i = e / 10, j = e % 10;
+        double acc = 0.0;
+        for (int k = 0; k < 10; k++) acc += F[i * 10 + k] * P[k * 10 + j];
+        T[e] = acc;
+    }
+    wave_sync();
+    for (int e = lane; e < 100; e += WAVE) {
+        const int i = e / 10, j = e % 10;
+        double acc = 0.0;
+        for (int k = 0; k < 10; k++) acc += T[i * 10 + k] * F[j * 10 + k];
+        P[e] = acc + (i == j ? qd[i] : 0.0);
+    }
+    if (lane < 10) {
+        double xv = x[0], dv = xd[0];
+#pragma unroll
+        for (int i = 1; i < 10; i++) { xv = (lane == i) ? x[i] : xv; dv = (lane == i) ? xd[i] : dv; }
+        xe[lane] = dv * dt + xv;
+    }
+    wave_sync();
+}
+
+// EKF.py:45-49,65-74: K = solve(S', (P H')')' with S = H P H' + R, x += K (y - H x), P -= K H P.  The 7x7 system with
+// its 10 right-hand sides is eliminated in LDS with partial pivoting (what numpy.linalg.solve does).
+__device__ __forceinline__ void ekf_measurement_update_wave(int lane, double *xe, double *P, double *T, double *Aug,
+                                                            const double *y, const double *rd)
+{
+    // Aug[a][0..6] = S'[a][:], Aug[a][7 + i] = (P H')[i][a]
+    for (int e = lane; e < 7 * 17; e += WAVE) {
+        const int a = e / 17, c = e % 17;
+        Aug[e] = (c < 7) ? P[c_meas[c] * 10 + c_meas[a]] + (a == c ? rd[a] : 0.0) : P[(c - 7) * 10 + c_meas[a]];
+    }
+    wave_sync();
+    for (int c = 0; c < 7; c++) {
+        int piv = c;
+        double best = fabs(Aug[c * 17 + c]);
+        for (int r = c + 1; r < 7; r++) {
+            const double v = fabs(Aug[r * 17 + c]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (piv != c && lane < 17) {
+            const double t = Aug[c * 17 + lane];
+            Aug[c * 17 + lane] = Aug[piv * 17 + lane];
+            Aug[piv * 17 + lane] = t;
+        }
+        wave_sync();
+        const double pc = Aug[c * 17 + c];
+        double f[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) f[r] = (r > c) ? Aug[r * 17 + c] / pc : 0.0;
+        wave_sync();
+        if (lane < 17 && lane >= c) {
+            const double top = Aug[c * 17 + lane];
+#pragma unroll
+            for (int r = 0; r < 7; r++)
+                if (r > c) Aug[r * 17 + lane] -= f[r] * top;
+        }
+        wave_sync();
+    }
+    if (lane < 10) {   // back substitution of right-hand side `lane`; K[lane][a] ends up in Aug[a][7 + lane]
+        for (int c = 6; c >= 0; c--) {
+            double acc = Aug[c * 17 + 7 + lane];
+            for (int k = c + 1; k < 7; k++) acc -= Aug[c * 17 + k] * Aug[k * 17 + 7 + lane];
+            Aug[c * 17 + 7 + lane] = acc / Aug[c * 17 + c];
+        }
+    }
+    wave_sync();
+    for (int e = lane; e < 100; e += WAVE) {
+        const int i = e / 10, j = e % 10;
+        double acc = 0.0;
+        for (int a = 0; a < 7; a++) acc += Aug[a * 17 + 7 + i] * P[c_meas[a] * 10 + j];
+        T[e] = P[e] - acc;
+    }
+    double dx = 0.0;
+    if (lane < 10)
+        for (int a = 0; a < 7; a++) dx += Aug[a * 17 + 7 + lane] * (y[a] - xe[c_meas[a]]);
+    wave_sync();
+    for (int e = lane; e < 100; e += WAVE) P[e] = T[e];
+    if (lane < 10) xe[lane] += dx;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W]
 template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W; }
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
@@ -366,9 +466,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
     const int ncomp = __popc(a.sh_mask & 7);
     double *s_K = lds;
     double *s_Kx = lds + (GENERAL ? 0 : ncomp * N * N);
-    double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_lds_doubles<N>();
+    const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+    double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
-    double *s_wv = GENERAL ? wbase + wave_lds_doubles<N>() : nullptr;
+    double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
+    double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
     if (GENERAL) {
         if (lane < 36) s_We[lane] = cfg.We[lane];
@@ -397,14 +499,21 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
     const double f35 = dt * (-mp.Cf / mp.m), f45 = dt * (-mp.lf * mp.Cf / mp.Iz);
 
     // closed-loop state lives in registers across the steps of one launch
-    double plant[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double plant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the 8-state plant is the 10-state one with zero disturbances
     double prevp = 0.0, tvel = 0.0;
     int lapv = 0;
+    const int nxp = a.nx_plant;
+    double *s_xe = s_ekf, *s_P = s_ekf + 10, *s_F = s_ekf + 110, *s_T = s_ekf + 210, *s_aug = s_ekf + 310;
     if (a.mode != MODE_SOLVE) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) plant[i] = a.state[8 * (size_t)s + i];
+        for (int i = 0; i < 10; i++) plant[i] = (i < nxp) ? a.state[(size_t)nxp * s + i] : 0.0;
         tvel = a.target_vel[s];
         if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
+        if (a.mode == MODE_OFL) {
+            for (int e = lane; e < 100; e += WAVE) s_P[e] = a.ekf_P[(size_t)s * 100 + e];
+            if (lane < 10) s_xe[lane] = a.ekf_x[(size_t)s * 10 + lane];
+            wave_sync();
+        }
     }
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0;
@@ -425,23 +534,30 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
                 s_p[k] = a.p[(size_t)s * (N + 1) + k];
             }
         } else {
+            // pose and controller start come from the plant state, or from the EKF estimate in the output-feedback
+            // loop (simulator.py:230-251: estimated_red_state, d_est = x_est[9])
+            double px = plant[0], py = plant[1], hc = plant[2], hs = plant[3];
             xh3 = plant[5]; xh4 = plant[6]; xh5 = plant[7];
-            const double heading = atan2(plant[3], plant[2]);              // skidpad_simulator.py:104
+            if (a.mode == MODE_OFL) {
+                px = s_xe[0]; py = s_xe[1]; hc = s_xe[2]; hs = s_xe[3];
+                xh3 = s_xe[5]; xh4 = s_xe[6]; xh5 = s_xe[7]; dhat = s_xe[9];
+            }
+            const double heading = atan2(hs, hc);                          // skidpad_simulator.py:104
             double p0;
             if (a.mode == MODE_SKIDPAD) {
                 int lp = lapv;
-                p0 = sk_pos2progress(plant[0], plant[1], lp);
-                if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(plant[0], plant[1], lp); }
+                p0 = sk_pos2progress(px, py, lp);
+                if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
                 prevp = p0;                                                // path_planning.py:251
             } else
-                p0 = plant[0];                                             // step_planning.py:83-86
+                p0 = px;                                                   // step_planning.py:83-86
             const double ch = cos(heading), sh = sin(heading);
             for (int k = lane; k <= N; k += WAVE) {
                 double o[4];
                 const double q = waypoint_progress(p0, tvel, dt, k);
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
                 else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }   // step_planning.py:63-80
-                to_car_frame(o, plant[0], plant[1], ch, sh);
+                to_car_frame(o, px, py, ch, sh);
                 s_ref[k] = o[0]; s_ref[(N + 1) + k] = o[1]; s_ref[2 * (N + 1) + k] = o[3];
                 s_p[k] = tvel;
                 if (a.wp_out) {
@@ -593,27 +709,42 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
         }
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
-            plant_rk4<8>(plant, u0, dt, mp);                                // skidpad_simulator.py:128
+            plant_rk4<10>(plant, u0, dt, mp);                               // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
-            if (a.x_hist && lane < 8) {
+            if (a.x_hist && lane < nxp) {
                 double val = plant[0];
 #pragma unroll
-                for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
-                a.x_hist[((size_t)t * a.B + s) * 8 + lane] = val;
+                for (int i = 1; i < 10; i++) val = (lane == i) ? plant[i] : val;
+                a.x_hist[((size_t)t * a.B + s) * nxp + lane] = val;
+            }
+            if (a.mode == MODE_OFL) {                                       // simulator.py:262-272
+                ekf_time_update_wave(lane, s_xe, s_P, s_F, s_T, u0, dt, mp, a.ekf_q);
+                double y[7];
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    y[c] = plant[c < 5 ? c : c + 1];
+                    if (a.meas_noise) y[c] += a.meas_noise[((size_t)t * a.B + s) * 7 + c];
+                }
+                ekf_measurement_update_wave(lane, s_xe, s_P, s_T, s_aug, y, a.ekf_r);
+                if (a.est_hist && lane < 10) a.est_hist[((size_t)t * a.B + s) * 10 + lane] = s_xe[lane];
             }
         }
         wave_sync();
     }   // steps of this launch
 
     if (a.mode != MODE_SOLVE) {
-        if (lane < 8) {
+        if (lane < nxp) {
             double val = plant[0];
 #pragma unroll
-            for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
-            a.state[8 * (size_t)s + lane] = val;
+            for (int i = 1; i < 10; i++) val = (lane == i) ? plant[i] : val;
+            a.state[(size_t)nxp * s + lane] = val;
         }
         if (a.mode == MODE_SKIDPAD && lane == 0) { a.lap[s] = lapv; a.prev_progress[s] = prevp; }
+        if (a.mode == MODE_OFL) {
+            for (int e = lane; e < 100; e += WAVE) a.ekf_P[(size_t)s * 100 + e] = s_P[e];
+            if (lane < 10) a.ekf_x[(size_t)s * 10 + lane] = s_xe[lane];
+        }
     }
     if (lane == 0) {
         if (a.u0_out) a.u0_out[s] = u0;
@@ -698,7 +829,8 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
 {
     if (a.sh_H && a.sh_exclusive) {
         const int ncomp = __builtin_popcount(a.sh_mask & 7);
-        const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_lds_doubles<N>());
+        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+        const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_area);
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc<N, false>),
@@ -708,7 +840,8 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         }
         hipLaunchKernelGGL((k_mpc<N, false>), dim3((a.B + FIXED_WPB - 1) / FIXED_WPB), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
-        const size_t lds = sizeof(double) * (size_t)(wave_lds_doubles<N>() + 6 * N + 36);
+        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+        const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36);
         hipLaunchKernelGGL((k_mpc<N, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
     }
     return hipGetLastError();

@@ -171,6 +171,37 @@ def test_step_simulator_output_feedback(orc64):
     assert path.shape == (n, 2)
 
 
+def test_batched_output_feedback_loop_fused(orc64):
+    """mpc_ofl_closed_loop_run: planner + OFL solve + 10-state plant + EKF fused per scenario, several disturbance levels,
+    with and without measurement noise, against the loop composed from checker primitives."""
+    from oracle import oracle as O
+    from mpc_amd.batched import StepOFLBatch
+    N, Tf, n = 50, 0.5, 25
+    rng = np.random.default_rng(2)
+    B = 6
+    true0 = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, -10.0]), (B, 1))
+    true0[:, 9] = rng.uniform(-12, -8, B); true0[:, 1] = rng.uniform(-0.1, 0.1, B)
+    est0 = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (B, 1))
+    est0[:, 1] += rng.normal(0, 0.05, B)
+    for cached in (True, False):
+        sim = StepOFLBatch(N, Tf, true0, est0, fixed_model_cache=cached)
+        xs, us, es = sim.run(n, record=True)
+        xs, us, es = xs.cpu().numpy(), us.cpu().numpy(), es.cpu().numpy()
+        assert (sim.status.cpu().numpy() == 0).all()
+        for b in range(B):
+            xr, ur, er = _oracle_of_loop(orc64, n, N, Tf, list(true0[b]), list(est0[b]))
+            assert (np.abs(us[:, b] - ur) <= 10 * _utol(ur)).all(), (cached, b, np.abs(us[:, b] - ur).max())
+            np.testing.assert_allclose(xs[:, b], xr, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(es[:, b], er, rtol=1e-6, atol=1e-6)
+    # with noise: the estimate must stay finite and the run must be reproducible for the same noise tensor
+    noise = rng.normal(0, 1, (n, B, 7)) * np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])
+    a = StepOFLBatch(N, Tf, true0, est0); b2 = StepOFLBatch(N, Tf, true0, est0)
+    ra = a.run(n, record=True, meas_noise=noise); rb = b2.run(n, record=True, meas_noise=noise)
+    assert np.isfinite(ra[2].cpu().numpy()).all()
+    for p_, q_ in zip(ra, rb):
+        np.testing.assert_array_equal(p_.cpu().numpy(), q_.cpu().numpy())
+
+
 def test_step_simulator_simulate_lsim_dlqr(orc64, golden):
     from oracle import oracle as O
     from mpc_amd.simulator import StepSimulator
