@@ -33,7 +33,7 @@ extern "C" {
 #define MPC_PLANNER_SKIDPAD 0 /* utils/path_planning.py SkidpadPlanner */
 #define MPC_PLANNER_STEP 1    /* utils/step_planning.py StepPlanner    */
 
-#define MPC_MAX_HORIZON 64
+#define MPC_MAX_HORIZON 128
 
 /* Controller definition; what the reference's constructors derive from parameters_*.yaml
  * (LMPC2.py:14-96, LPVMPC.py:10-92, OFLMPC2.py:16-100). */
@@ -71,7 +71,8 @@ int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario);
  * is not exactly vx still take the per-scenario condensing path inside the same launch, unless `exclusive` is
  * set: then the caller promises that every scenario runs at vx, a leaner kernel without the per-scenario path is
  * launched, and a scenario that breaks the promise is not solved but reported with status 3.  vx = NaN switches
- * the cache off.  Plays the role of the one-time QP data set-up inside AcadosOcpSolver(ocp) (LMPC2.py:94). */
+ * the cache off.  Horizons without a register-resident kernel (anything but 10, 20, 30, 40, 50, 64) have no cache:
+ * the call succeeds and changes nothing, and those horizons keep condensing per scenario.  Plays the role of the one-time QP data set-up inside AcadosOcpSolver(ocp) (LMPC2.py:94). */
 int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
 
 /* optimize(): the yref/p set loop + solve_for_x0 + x/u get loop of LMPC2.py:296-347,

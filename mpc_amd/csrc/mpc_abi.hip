@@ -53,7 +53,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_LPV) return fail(nullptr, MPC_EINVAL, "mpc_create: unknown kind");
     if (!mpc::horizon_supported(cfg->N)) {
         char b[160];
-        snprintf(b, sizeof b, "mpc_create: horizon N=%d has no compiled solver in this build", cfg->N);
+        snprintf(b, sizeof b, "mpc_create: horizon N=%d is outside 2..%d", cfg->N, MPC_MAX_HORIZON);
         return fail(nullptr, MPC_EINVAL, b);
     }
     if (cfg->B < 1 || !(cfg->dt > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: need B >= 1 and dt > 0");
@@ -106,6 +106,8 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
     if (!h) return MPC_EINVAL;
     if (h->cfg.kind == MPC_KIND_LPV) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV model is re-linearised every step");
     if (!(vx == vx)) { h->sh_on = false; return MPC_OK; }   // NaN switches the cache off
+    // the cache belongs to the register-resident kernels; other horizons keep condensing per scenario (same results)
+    if (!mpc::horizon_templated(h->cfg.N)) { h->sh_on = false; return MPC_OK; }
     const size_t N = (size_t)h->cfg.N;
     if (!h->sh_H) {
         HIP_TRY(h, hipMalloc(&h->sh_H, N * N * sizeof(double)));

@@ -1,0 +1,602 @@
+// Any-horizon variant of the wave-per-scenario MPC step (N <= 128) for gfx950.
+//
+// Same algorithm and semantics as k_mpc in mpc_solver.hip (plan -> stage model -> condense -> unconstrained solve ->
+// interior point -> rollout -> plant/EKF), but the horizon is a run-time value: one wavefront owns a scenario, lane l
+// owns stages l and l + 64 (R = 2; R = 1 for N <= 64), and the Newton matrix lives in LDS instead of registers
+// (column-major, thread-contiguous, so the factorisation runs without bank conflicts and without unrolled code).
+// It serves horizons that have no register-resident instantiation, e.g. the LPV controller's N = 80
+// (plot_generator.py:604) or the N = 50..90 sweep of plot_generator.py:46-75.
+#include "mpc_wave.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace mpc {
+
+__device__ __forceinline__ double rl(double v, int src)   // readlane with a run-time (wave-uniform) lane index
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int R>
+struct Vec {
+    double v[R];
+    __device__ __forceinline__ double at(int i) const   // value of logical entry i (wave-uniform i)
+    {
+        if (R == 1) return rl(v[0], i);
+        return i < WAVE ? rl(v[0], i) : rl(v[R - 1], i - WAVE);
+    }
+};
+
+template <int R>
+__device__ __forceinline__ Vec<R> vprefix(const Vec<R> &x, int lane)   // inclusive prefix sums in logical order
+{
+    Vec<R> o;
+    double carry = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        o.v[q] = incl_prefix(x.v[q], lane) + carry;
+        carry = rl(o.v[q], WAVE - 1);
+    }
+    return o;
+}
+template <int R>
+__device__ __forceinline__ Vec<R> vsuffix(const Vec<R> &x, int lane)
+{
+    Vec<R> o;
+    double carry = 0.0;
+#pragma unroll
+    for (int q = R - 1; q >= 0; q--) {
+        o.v[q] = incl_suffix(x.v[q], lane) + carry;
+        carry = rl(o.v[q], 0);
+    }
+    return o;
+}
+template <int R> __device__ __forceinline__ double vmaxabs(const Vec<R> &x)
+{
+    double m = 0.0;
+#pragma unroll
+    for (int q = 0; q < R; q++) m = fmax(m, fabs(x.v[q]));
+    return wave_max(m);
+}
+
+// LDL' of the symmetric matrix whose lower triangle sits in M (column-major with leading dimension LD: entry (row i,
+// column j) at M[j*LD + i], i >= j).  Column k keeps c(i,k) = d(k) l(i,k); the factor mirrors it into the upper
+// triangle (M[i*LD + k]... stored as column i, row k) so that the backward substitution also reads thread-contiguously.
+template <int R>
+__device__ __forceinline__ void lds_factor(double *M, int LD, int N, int lane, double (&dinv)[R])
+{
+#pragma unroll
+    for (int q = 0; q < R; q++) dinv[q] = 1.0;
+    for (int k = 0; k < N; k++) {
+        const double inv = fast_rcp(M[k * LD + k]);
+        double l[R], c[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int i = lane + WAVE * q;
+            c[q] = (i > k && i < N) ? M[k * LD + i] : 0.0;
+            l[q] = c[q] * inv;
+            if (i == k) dinv[q] = inv;
+        }
+        for (int j = k + 1; j < N; j++) {
+            const double cj = M[k * LD + j];           // wave-uniform address: LDS broadcast
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                if (i >= j && i < N) M[j * LD + i] = fma(-l[q], cj, M[j * LD + i]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int i = lane + WAVE * q;
+            if (i > k && i < N) M[i * LD + k] = c[q];   // mirror: column i, row k
+        }
+        wave_sync();
+    }
+}
+
+template <int R>
+__device__ __forceinline__ Vec<R> lds_solve(const double *M, int LD, int N, int lane, const double (&dinv)[R], Vec<R> b)
+{
+    Vec<R> w = b;
+    for (int k = 0; k < N - 1; k++) {
+        const double wk = w.at(k) * fast_rcp(M[k * LD + k]);      // l(i,k) w_k = c(i,k) * (w_k / d_k)
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int i = lane + WAVE * q;
+            if (i > k && i < N) w.v[q] = fma(-M[k * LD + i], wk, w.v[q]);
+        }
+    }
+    // x_i = (w_i - sum_{k>i} c(k,i) x_k) / d_i, with c(k,i) read from the mirrored upper triangle
+    for (int k = N - 1; k > 0; k--) {
+        Vec<R> xs;
+#pragma unroll
+        for (int q = 0; q < R; q++) xs.v[q] = w.v[q] * dinv[q];
+        const double xk = xs.at(k);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int i = lane + WAVE * q;
+            if (i < k) w.v[q] = fma(-M[k * LD + i], xk, w.v[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) w.v[q] *= dinv[q];
+    return w;
+}
+
+template <int R>
+__global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveArgs a)
+{
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int N = cfg.N;
+    const int LD = N | 1;                 // odd leading dimension: the one strided access per pivot is 2-way at worst
+    extern __shared__ double lds[];
+    double *s_ref = lds, *s_p = s_ref + 3 * (N + 1), *s_stage = s_p + (N + 1), *s_wv = s_stage + N * STAGE_W;
+    double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_ekf = M + (size_t)N * LD;
+    if (lane < 36) s_We[lane] = cfg.We[lane];
+
+    ModelParams mp;
+    if (a.mp_scen) {
+        const double *q = a.mp_scen + 6 * (size_t)s;
+        mp = {q[0], q[1], q[2], q[3], q[4], q[5]};
+    } else
+        mp = {cfg.mp[0], cfg.mp[1], cfg.mp[2], cfg.mp[3], cfg.mp[4], cfg.mp[5]};
+    const double dt = cfg.dt, dt2 = dt * dt;
+    const double umax = cfg.max_rate, dmax = cfg.max_steering;
+    const double f35 = dt * (-mp.Cf / mp.m), f45 = dt * (-mp.lf * mp.Cf / mp.Iz);
+    double wq[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];
+    const double wr = dt * cfg.w[6];
+    bool valid[R], validd[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) { valid[q] = lane + WAVE * q < N; validd[q] = lane + WAVE * q < N - 1; }
+
+    double plant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double prevp = 0.0, tvel = 0.0;
+    int lapv = 0;
+    const int nxp = a.nx_plant;
+    double *s_xe = s_ekf, *s_P = s_ekf + 10, *s_F = s_ekf + 110, *s_T = s_ekf + 210, *s_aug = s_ekf + 310;
+    if (a.mode != MODE_SOLVE) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) plant[i] = (i < nxp) ? a.state[(size_t)nxp * s + i] : 0.0;
+        tvel = a.target_vel[s];
+        if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
+        if (a.mode == MODE_OFL) {
+            for (int e = lane; e < 100; e += WAVE) s_P[e] = a.ekf_P[(size_t)s * 100 + e];
+            if (lane < 10) s_xe[lane] = a.ekf_x[(size_t)s * 10 + lane];
+        }
+    }
+    wave_sync();
+    const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
+    int iters_tot = 0, status_max = 0, nconstr = 0;
+    double mu = 0.0, res = 0.0, u0 = 0.0;
+    double *Hg = a.Hws + (size_t)s * N * N;
+
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t++) {
+        // ------------------------------------------------------------ 1. initial state and references
+        double xh3, xh4, xh5, dhat = 0.0;
+        if (a.mode == MODE_SOLVE) {
+            const double *x0 = a.x0 + 7 * (size_t)s;
+            xh3 = x0[4]; xh4 = x0[5]; xh5 = x0[6];
+            if (a.d_hat) dhat = a.d_hat[s];
+            for (int k = lane; k <= N; k += WAVE) {
+                const double *w = a.wp + ((size_t)s * (N + 1) + k) * 4;
+                s_ref[k] = w[0]; s_ref[(N + 1) + k] = w[1]; s_ref[2 * (N + 1) + k] = w[3];
+                s_p[k] = a.p[(size_t)s * (N + 1) + k];
+            }
+        } else {
+            double px = plant[0], py = plant[1], hc = plant[2], hs = plant[3];
+            xh3 = plant[5]; xh4 = plant[6]; xh5 = plant[7];
+            if (a.mode == MODE_OFL) {
+                px = s_xe[0]; py = s_xe[1]; hc = s_xe[2]; hs = s_xe[3];
+                xh3 = s_xe[5]; xh4 = s_xe[6]; xh5 = s_xe[7]; dhat = s_xe[9];
+            }
+            const double heading = atan2(hs, hc);
+            double p0;
+            if (a.mode == MODE_SKIDPAD) {
+                int lp = lapv;
+                p0 = sk_pos2progress(px, py, lp);
+                if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
+                prevp = p0;
+            } else
+                p0 = px;
+            const double ch = cos(heading), sh = sin(heading);
+            for (int k = lane; k <= N; k += WAVE) {
+                double o[4];
+                const double q = waypoint_progress(p0, tvel, dt, k);
+                if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
+                else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+                to_car_frame(o, px, py, ch, sh);
+                s_ref[k] = o[0]; s_ref[(N + 1) + k] = o[1]; s_ref[2 * (N + 1) + k] = o[3];
+                s_p[k] = tvel;
+                if (a.wp_out) {
+                    double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
+                    w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+                }
+            }
+        }
+        wave_sync();
+
+        // ------------------------------------------------------------ 2. per-stage model
+        const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;
+        for (int k = lane; k < N; k += WAVE)
+            stage_model(cfg, mp, s_p[k], a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr, N, k, &s_stage[k * STAGE_W]);
+        for (int e = lane; e < N * LD; e += WAVE) M[e] = 0.0;
+        wave_sync();
+
+        // ------------------------------------------------------------ 3. condense into M (lower triangle) and g
+        Vec<R> g;
+        {
+            double v[R][6], xf[6] = {0, 0, 0, xh3, xh4, xh5};
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                g.v[q] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) v[q][c] = 0.0;
+            }
+#pragma unroll 1
+            for (int k = 1; k <= N; k++) {
+                const double *st = &s_stage[(k - 1) * STAGE_W];
+                const double e02 = st[0], e03 = st[1], e12 = st[2], e13 = st[3], f33 = st[4], f34 = st[5], f43 = st[6],
+                             f44 = st[7], c0 = st[8], c1 = st[9];
+                {
+                    const double n0 = xf[0] + e02 * xf[2] + e03 * xf[3] + c0;
+                    const double n1 = xf[1] + e12 * xf[2] + e13 * xf[3] + c1;
+                    const double n2 = xf[2] + dt * xf[4];
+                    const double n3 = f33 * xf[3] + f34 * xf[4] + f35 * xf[5] + c3;
+                    const double n4 = f43 * xf[3] + f44 * xf[4] + f45 * xf[5];
+                    xf[0] = n0; xf[1] = n1; xf[2] = n2; xf[3] = n3; xf[4] = n4;
+                }
+                double err[6] = {xf[0], xf[1], xf[2], xf[3], xf[4], xf[5]};
+                if (!(k == N && cfg.kind == MPC_KIND_LPV)) {
+                    err[0] -= s_ref[k]; err[1] -= s_ref[(N + 1) + k]; err[2] -= s_ref[2 * (N + 1) + k];
+                }
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int i = lane + WAVE * q;
+                    double *vv = v[q];
+                    const double n0 = vv[0] + e02 * vv[2] + e03 * vv[3];
+                    const double n1 = vv[1] + e12 * vv[2] + e13 * vv[3];
+                    const double n2 = vv[2] + dt * vv[4];
+                    const double n3 = f33 * vv[3] + f34 * vv[4] + f35 * vv[5];
+                    const double n4 = f43 * vv[3] + f44 * vv[4] + f45 * vv[5];
+                    vv[0] = n0; vv[1] = n1; vv[2] = n2; vv[3] = n3; vv[4] = n4;
+                    if (i == k - 1) { vv[0] = 0; vv[1] = 0; vv[2] = 0; vv[3] = 0; vv[4] = 0; vv[5] = dt; }
+                    double wv[6];
+                    if (k < N) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) wv[c] = wq[c] * vv[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            double tt = 0.0;
+#pragma unroll
+                            for (int d = 0; d < 6; d++) tt = fma(s_We[d * 6 + c], vv[d], tt);
+                            wv[c] = tt;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) g.v[q] = fma(wv[c], err[c], g.v[q]);
+                    if (i < N) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) s_wv[c * N + i] = wv[c];
+                    }
+                }
+                wave_sync();
+                // M(i,j) += (W v_j)' v_i for j <= i < k (entries with i or j >= k are still zero)
+                for (int j = 0; j < k; j++) {
+                    double wj[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) wj[c] = (k == N || wq[c] != 0.0) ? s_wv[c * N + j] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        const int i = lane + WAVE * q;
+                        if (i >= j && i < k) {
+                            double acc = M[j * LD + i];
+#pragma unroll
+                            for (int c = 0; c < 6; c++) acc = fma(wj[c], v[q][c], acc);
+                            M[j * LD + i] = acc;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int i = lane + WAVE * q;
+            if (i < N) M[i * LD + i] += wr;
+            else g.v[q] = 0.0;
+        }
+        wave_sync();
+        // keep H in the workspace (full symmetric, row stride N) for the interior-point iterations
+        for (int j = 0; j < N; j++) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                if (i >= j && i < N) { const double h = M[j * LD + i]; Hg[j * N + i] = h; Hg[i * N + j] = h; }
+            }
+        }
+        __threadfence_block();
+        wave_sync();
+
+        // ------------------------------------------------------------ 4. solve
+        const double up_d = dmax - xh5, lo_d = -dmax - xh5;
+        double dinv[R];
+        lds_factor<R>(M, LD, N, lane, dinv);
+        Vec<R> U;
+        int iters = 0, status = 0, constrained = 0;
+        {
+            Vec<R> rhs;
+#pragma unroll
+            for (int q = 0; q < R; q++) rhs.v[q] = -g.v[q];
+            Vec<R> Uu = lds_solve<R>(M, LD, N, lane, dinv, rhs);
+#pragma unroll
+            for (int q = 0; q < R; q++) if (!valid[q]) Uu.v[q] = 0.0;
+            const Vec<R> vd = vprefix<R>(Uu, lane);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                ok = ok && fabs(Uu.v[q]) <= umax;
+                if (validd[q]) ok = ok && (dt * vd.v[q] <= up_d) && (dt * vd.v[q] >= lo_d);
+            }
+            if (__all(ok)) U = Uu;
+            else constrained = 1;
+        }
+        if (constrained) {
+            const double gscale = fmax(1.0, vmaxabs<R>(g));
+            Vec<R> tpu, tmu, lpu, lmu, tpd, tmd, lpd, lmd;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                U.v[q] = 0.0;
+                tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
+                lpu.v[q] = valid[q] ? 1.0 : 0.0; lmu.v[q] = lpu.v[q];
+                tpd.v[q] = validd[q] ? fmax(up_d, 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d, 0.1 * dmax) : 1.0;
+                lpd.v[q] = validd[q] ? 1.0 : 0.0; lmd.v[q] = lpd.v[q];
+            }
+            const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
+            double res_prev = 1e300;
+#pragma unroll 1
+            for (;;) {
+                Vec<R> hu;
+#pragma unroll
+                for (int q = 0; q < R; q++) hu.v[q] = 0.0;
+                for (int j = 0; j < N; j++) {
+                    const double uj = U.at(j);
+#pragma unroll
+                    for (int q = 0; q < R; q++) if (valid[q]) hu.v[q] = fma(Hg[j * N + lane + WAVE * q], uj, hu.v[q]);
+                }
+                const Vec<R> vd = vprefix<R>(U, lane);
+                Vec<R> lamd;
+#pragma unroll
+                for (int q = 0; q < R; q++) lamd.v[q] = validd[q] ? lpd.v[q] - lmd.v[q] : 0.0;
+                const Vec<R> sl = vsuffix<R>(lamd, lane);
+                Vec<R> rd, rppu, rpmu, rppd, rpmd;
+                double musum = 0.0, rpmax = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    rd.v[q] = valid[q] ? hu.v[q] + g.v[q] + (lpu.v[q] - lmu.v[q]) + dt * sl.v[q] : 0.0;
+                    rppu.v[q] = valid[q] ? U.v[q] + tpu.v[q] - umax : 0.0; rpmu.v[q] = valid[q] ? -U.v[q] + tmu.v[q] - umax : 0.0;
+                    rppd.v[q] = validd[q] ? dt * vd.v[q] + tpd.v[q] - up_d : 0.0;
+                    rpmd.v[q] = validd[q] ? -dt * vd.v[q] + tmd.v[q] + lo_d : 0.0;
+                    musum += tpu.v[q] * lpu.v[q] + tmu.v[q] * lmu.v[q] + tpd.v[q] * lpd.v[q] + tmd.v[q] * lmd.v[q];
+                    rpmax = fmax(rpmax, fmax(fmax(fabs(rppu.v[q]), fabs(rpmu.v[q])), fmax(fabs(rppd.v[q]), fabs(rpmd.v[q]))));
+                }
+                mu = wave_sum(musum) * inv_nc;
+                res = fmax(vmaxabs<R>(rd) / gscale, wave_max(rpmax));
+                if (mu <= cfg.tol_mu && (res <= cfg.tol_res || res >= 0.5 * res_prev)) break;
+                if (iters >= cfg.max_iter) { status = 2; break; }
+                res_prev = res;
+                Vec<R> Du, Dd;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    Du.v[q] = lpu.v[q] / tpu.v[q] + lmu.v[q] / tmu.v[q];
+                    Dd.v[q] = validd[q] ? lpd.v[q] / tpd.v[q] + lmd.v[q] / tmd.v[q] : 0.0;
+                }
+                const Vec<R> sfx = vsuffix<R>(Dd, lane);
+                for (int j = 0; j < N; j++) {       // lower triangle: max(i,j) = i
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        const int i = lane + WAVE * q;
+                        if (i >= j && i < N) M[j * LD + i] = fma(dt2, sfx.v[q], Hg[j * N + i]) + (i == j ? Du.v[q] : 0.0);
+                    }
+                }
+                wave_sync();
+                lds_factor<R>(M, LD, N, lane, dinv);
+                Vec<R> dU, dtpu, dtmu, dlpu, dlmu, dtpd, dtmd, dlpd, dlmd;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    dU.v[q] = 0; dtpu.v[q] = 0; dtmu.v[q] = 0; dlpu.v[q] = 0; dlmu.v[q] = 0;
+                    dtpd.v[q] = 0; dtmd.v[q] = 0; dlpd.v[q] = 0; dlmd.v[q] = 0;
+                }
+                double sigmu = 0.0, alpha = 1.0;
+#pragma unroll 1
+                for (int pass = 0; pass < 2; pass++) {
+                    Vec<R> rcpu, rcmu, rcpd, rcmd, wd, rhs;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        rcpu.v[q] = tpu.v[q] * lpu.v[q]; rcmu.v[q] = tmu.v[q] * lmu.v[q];
+                        rcpd.v[q] = tpd.v[q] * lpd.v[q]; rcmd.v[q] = tmd.v[q] * lmd.v[q];
+                        if (pass) {
+                            rcpu.v[q] += dtpu.v[q] * dlpu.v[q] - sigmu; rcmu.v[q] += dtmu.v[q] * dlmu.v[q] - sigmu;
+                            rcpd.v[q] += dtpd.v[q] * dlpd.v[q] - sigmu; rcmd.v[q] += dtmd.v[q] * dlmd.v[q] - sigmu;
+                        }
+                        wd.v[q] = validd[q] ? (lpd.v[q] * rppd.v[q] - rcpd.v[q]) / tpd.v[q] - (lmd.v[q] * rpmd.v[q] - rcmd.v[q]) / tmd.v[q] : 0.0;
+                    }
+                    const Vec<R> sw = vsuffix<R>(wd, lane);
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        const double wu = (lpu.v[q] * rppu.v[q] - rcpu.v[q]) / tpu.v[q] - (lmu.v[q] * rpmu.v[q] - rcmu.v[q]) / tmu.v[q];
+                        rhs.v[q] = valid[q] ? -rd.v[q] - wu - dt * sw.v[q] : 0.0;
+                    }
+                    dU = lds_solve<R>(M, LD, N, lane, dinv, rhs);
+#pragma unroll
+                    for (int q = 0; q < R; q++) if (!valid[q]) dU.v[q] = 0.0;
+                    const Vec<R> dvd = vprefix<R>(dU, lane);
+                    double al = 1.0;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        dtpu.v[q] = -rppu.v[q] - dU.v[q]; dtmu.v[q] = -rpmu.v[q] + dU.v[q];
+                        dlpu.v[q] = -(rcpu.v[q] + lpu.v[q] * dtpu.v[q]) / tpu.v[q]; dlmu.v[q] = -(rcmu.v[q] + lmu.v[q] * dtmu.v[q]) / tmu.v[q];
+                        dtpd.v[q] = -rppd.v[q] - dt * dvd.v[q]; dtmd.v[q] = -rpmd.v[q] + dt * dvd.v[q];
+                        dlpd.v[q] = -(rcpd.v[q] + lpd.v[q] * dtpd.v[q]) / tpd.v[q]; dlmd.v[q] = -(rcmd.v[q] + lmd.v[q] * dtmd.v[q]) / tmd.v[q];
+                        if (!valid[q]) { dtpu.v[q] = 0; dtmu.v[q] = 0; dlpu.v[q] = 0; dlmu.v[q] = 0; }
+                        if (!validd[q]) { dtpd.v[q] = 0; dtmd.v[q] = 0; dlpd.v[q] = 0; dlmd.v[q] = 0; }
+                        if (dtpu.v[q] < 0) al = fmin(al, -tpu.v[q] / dtpu.v[q]);
+                        if (dtmu.v[q] < 0) al = fmin(al, -tmu.v[q] / dtmu.v[q]);
+                        if (dlpu.v[q] < 0) al = fmin(al, -lpu.v[q] / dlpu.v[q]);
+                        if (dlmu.v[q] < 0) al = fmin(al, -lmu.v[q] / dlmu.v[q]);
+                        if (dtpd.v[q] < 0) al = fmin(al, -tpd.v[q] / dtpd.v[q]);
+                        if (dtmd.v[q] < 0) al = fmin(al, -tmd.v[q] / dtmd.v[q]);
+                        if (dlpd.v[q] < 0) al = fmin(al, -lpd.v[q] / dlpd.v[q]);
+                        if (dlmd.v[q] < 0) al = fmin(al, -lmd.v[q] / dlmd.v[q]);
+                    }
+                    alpha = wave_min(al);
+                    if (pass == 0) {
+                        double ms = 0.0;
+#pragma unroll
+                        for (int q = 0; q < R; q++)
+                            ms += (tpu.v[q] + alpha * dtpu.v[q]) * (lpu.v[q] + alpha * dlpu.v[q]) + (tmu.v[q] + alpha * dtmu.v[q]) * (lmu.v[q] + alpha * dlmu.v[q]) +
+                                  (tpd.v[q] + alpha * dtpd.v[q]) * (lpd.v[q] + alpha * dlpd.v[q]) + (tmd.v[q] + alpha * dtmd.v[q]) * (lmd.v[q] + alpha * dlmd.v[q]);
+                        const double sg = wave_sum(ms) * inv_nc / mu;
+                        sigmu = sg * sg * sg * mu;
+                    }
+                }
+                alpha *= 0.995;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    U.v[q] = fma(alpha, dU.v[q], U.v[q]);
+                    tpu.v[q] = fma(alpha, dtpu.v[q], tpu.v[q]); tmu.v[q] = fma(alpha, dtmu.v[q], tmu.v[q]);
+                    lpu.v[q] = fma(alpha, dlpu.v[q], lpu.v[q]); lmu.v[q] = fma(alpha, dlmu.v[q], lmu.v[q]);
+                    tpd.v[q] = fma(alpha, dtpd.v[q], tpd.v[q]); tmd.v[q] = fma(alpha, dtmd.v[q], tmd.v[q]);
+                    lpd.v[q] = fma(alpha, dlpd.v[q], lpd.v[q]); lmd.v[q] = fma(alpha, dlmd.v[q], lmd.v[q]);
+                }
+                iters++;
+            }
+        }
+
+        // ------------------------------------------------------------ 5. outputs, prediction, plant, estimator
+#pragma unroll
+        for (int q = 0; q < R; q++)
+            if (valid[q] && a.U_out) a.U_out[(size_t)s * N + lane + WAVE * q] = U.v[q];
+        u0 = rl(U.v[0], 0);
+        iters_tot += iters; status_max = max(status_max, status); nconstr += constrained;
+        if (a.traj_out || cfg.kind == MPC_KIND_LPV) {
+            double x[6] = {0, 0, 0, xh3, xh4, xh5};
+            double *lx = cfg.kind == MPC_KIND_LPV ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr;
+            for (int k = 0; k <= N; k++) {
+                if (lane == 0) {          // one lane writes stage k; the rollout itself is wave-uniform
+                    if (a.traj_out) {
+                        double *o = a.traj_out + ((size_t)s * (N + 1) + k) * 7;
+                        o[0] = x[0]; o[1] = x[1]; o[2] = cos(x[2]); o[3] = sin(x[2]); o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
+                    }
+                    if (lx) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) lx[c * (N + 1) + k] = x[c];
+                    }
+                }
+                if (k == N) break;
+                const double *st = &s_stage[k * STAGE_W];
+                const double uk = U.at(k);
+                const double n0 = x[0] + st[0] * x[2] + st[1] * x[3] + st[8];
+                const double n1 = x[1] + st[2] * x[2] + st[3] * x[3] + st[9];
+                const double n2 = x[2] + dt * x[4];
+                const double n3 = st[4] * x[3] + st[5] * x[4] + f35 * x[5] + c3;
+                const double n4 = st[6] * x[3] + st[7] * x[4] + f45 * x[5];
+                const double n5 = x[5] + dt * uk;
+                x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3; x[4] = n4; x[5] = n5;
+            }
+            if (lx) {
+#pragma unroll
+                for (int q = 0; q < R; q++)
+                    if (valid[q]) a.lin_u[(size_t)s * N + lane + WAVE * q] = U.v[q];
+            }
+        }
+        if (a.mode != MODE_SOLVE) {
+            const double oldx = plant[0];
+            plant_rk4<10>(plant, u0, dt, mp);
+            if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
+            if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
+            if (a.x_hist && lane < nxp) {
+                double val = plant[0];
+#pragma unroll
+                for (int i = 1; i < 10; i++) val = (lane == i) ? plant[i] : val;
+                a.x_hist[((size_t)t * a.B + s) * nxp + lane] = val;
+            }
+            if (a.mode == MODE_OFL) {
+                ekf_time_update_wave(lane, s_xe, s_P, s_F, s_T, u0, dt, mp, a.ekf_q);
+                double y[7];
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    y[c] = plant[c < 5 ? c : c + 1];
+                    if (a.meas_noise) y[c] += a.meas_noise[((size_t)t * a.B + s) * 7 + c];
+                }
+                ekf_measurement_update_wave(lane, s_xe, s_P, s_T, s_aug, y, a.ekf_r);
+                if (a.est_hist && lane < 10) a.est_hist[((size_t)t * a.B + s) * 10 + lane] = s_xe[lane];
+            }
+        }
+        __threadfence_block();
+        wave_sync();
+    }
+
+    if (a.mode != MODE_SOLVE) {
+        if (lane < nxp) {
+            double val = plant[0];
+#pragma unroll
+            for (int i = 1; i < 10; i++) val = (lane == i) ? plant[i] : val;
+            a.state[(size_t)nxp * s + lane] = val;
+        }
+        if (a.mode == MODE_SKIDPAD && lane == 0) { a.lap[s] = lapv; a.prev_progress[s] = prevp; }
+        if (a.mode == MODE_OFL) {
+            for (int e = lane; e < 100; e += WAVE) a.ekf_P[(size_t)s * 100 + e] = s_P[e];
+            if (lane < 10) a.ekf_x[(size_t)s * 10 + lane] = s_xe[lane];
+        }
+    }
+    if (lane == 0) {
+        if (a.u0_out) a.u0_out[s] = u0;
+        if (a.status_out) a.status_out[s] = status_max;
+        if (a.iters_out) a.iters_out[s] = iters_tot;
+        if (a.stat_out) {
+            double *so = a.stat_out + 4 * (size_t)s;
+            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+        }
+    }
+}
+
+static size_t any_lds_bytes(int N, int mode)
+{
+    const int LD = N | 1;
+    return sizeof(double) * ((size_t)4 * (N + 1) + (size_t)N * STAGE_W + 6 * (size_t)N + 36 + (size_t)N * LD +
+                             (mode == MODE_OFL ? EKF_LDS : 0));
+}
+
+hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
+{
+    if (cfg.N < 2 || cfg.N > MPC_MAX_HORIZON) return hipErrorInvalidValue;
+    const size_t lds = any_lds_bytes(cfg.N, a.mode);
+    static bool attr1 = false, attr2 = false;
+    if (cfg.N <= WAVE) {
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc_any<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(k_mpc_any<1>, dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+    } else {
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc_any<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(k_mpc_any<2>, dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mpc

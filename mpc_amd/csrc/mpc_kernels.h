@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/mpc_amd.h"
 
-// Horizons with a compiled solver (the Newton-matrix row of a lane lives in N statically indexed registers).
+// Horizons with a register-resident solver (the Newton-matrix row of a lane lives in N statically indexed registers);
+// every other horizon up to MPC_MAX_HORIZON runs on the any-horizon kernel, whose Newton matrix lives in LDS.
 #ifndef MPC_HORIZONS
 #define MPC_HORIZONS(X) X(10) X(20) X(30) X(40) X(50) X(64)
 #endif
@@ -47,8 +48,10 @@ struct SolveArgs {
 };
 
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
+hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);   // run-time horizon, no cache
 hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
-bool horizon_supported(int N);
+bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
+bool horizon_templated(int N);    // has a register-resident instantiation (and with it the fixed-model cache)
 
 hipError_t launch_plant_rk4(hipStream_t st, int B, int nx, double dt, const double *mp6, double *x, const double *u);
 hipError_t launch_plant_f(hipStream_t st, int B, int nx, const double *mp6, const double *x, const double *u, double *xd);

@@ -67,7 +67,7 @@ class Oracle:
         L.orc_skidpad_run.restype = C.c_long
         self.precision = precision
         # default solver tolerances: as tight as the arithmetic allows
-        self.tol = (1e-13, 1e-10, 100) if precision == "f64" else (1e-17, 1e-14, 200)
+        self.tol = (1e-13, 1e-15, 100) if precision == "f64" else (1e-17, 1e-18, 200)
 
     # -- set-up ---------------------------------------------------------
     def tyre_stiffness(self, m, x_cg):

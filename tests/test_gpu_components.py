@@ -115,13 +115,23 @@ def test_lpv_controller_sequence(orc80):
     from oracle import oracle as O
     from mpc_amd.controllers import LPVOcp
     from mpc_amd.skidpad_simulator import SkidpadSimulator
-    N, Tf = 50, 0.5
+    _lpv_sequence(orc80, 50, 0.5)
+
+
+def test_lpv_controller_sequence_horizon_80(orc80):
+    """The LPV controller at its canonical N = 80, Tf = 0.8 (plot_generator.py:604): runs on the any-horizon kernel."""
+    _lpv_sequence(orc80, 80, 0.8, nsteps=6)
+
+
+def _lpv_sequence(orc80, N, Tf, nsteps=12):
+    from oracle import oracle as O
+    from mpc_amd.controllers import LPVOcp
     for mode in ("reference", "prev_iter"):
         cfg = O.make_cfg("LPV", N, Tf, lin_mode=mode)
         ctl = LPVOcp(N, Tf)
         lin_x = np.zeros((6, N + 1)); lin_u = np.zeros(N)
         st = np.array([15.0, 0.25, np.cos(0.05), np.sin(0.05), 8.0, 0.1, -0.1, 0.02]); lap = 0; pp = 0.0
-        for i in range(12):
+        for i in range(nsteps):
             hd = np.arctan2(st[3], st[2])
             wp, sp, p0, pp = orc80.skidpad_waypoints(st[0], st[1], hd, lap, pp, 8.0, N, Tf / N)
             red = st[[0, 1, 2, 3, 5, 6, 7]]
@@ -202,6 +212,23 @@ def test_batched_output_feedback_loop_fused(orc64):
         np.testing.assert_array_equal(p_.cpu().numpy(), q_.cpu().numpy())
 
 
+def test_batched_output_feedback_loop_any_horizon(orc64):
+    """The fused output-feedback loop at a horizon without a register-resident kernel (N = 70)."""
+    from mpc_amd.batched import StepOFLBatch
+    N, Tf, n, B = 70, 0.7, 12, 3
+    true0 = np.tile(np.array([-5.0, 0.05, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, -10.0]), (B, 1))
+    true0[:, 9] = [-12.0, -10.0, -8.0]
+    est0 = true0.copy(); est0[:, 9] = 0.0
+    sim = StepOFLBatch(N, Tf, true0, est0)
+    xs, us, es = (t.cpu().numpy() for t in sim.run(n, record=True))
+    assert (sim.status.cpu().numpy() == 0).all()
+    for b in range(B):
+        xr, ur, er = _oracle_of_loop(orc64, n, N, Tf, list(true0[b]), list(est0[b]))
+        assert (np.abs(us[:, b] - ur) <= 10 * _utol(ur)).all(), (b, np.abs(us[:, b] - ur).max())
+        np.testing.assert_allclose(xs[:, b], xr, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(es[:, b], er, rtol=1e-6, atol=1e-6)
+
+
 def test_step_simulator_simulate_lsim_dlqr(orc64, golden):
     from oracle import oracle as O
     from mpc_amd.simulator import StepSimulator
@@ -240,7 +267,7 @@ def test_library_error_paths():
     """Argument checks of the C ABI: unsupported horizon, oversize batch, missing buffers raise with a message."""
     from mpc_amd.controllers import LOcp
     with pytest.raises(RuntimeError, match="horizon"):
-        LOcp(51, 0.51)
+        LOcp(129, 1.29)
     ctl = LOcp(10, 0.5, batch=2)
     with pytest.raises(ValueError, match="exceeds"):
         ctl.solve_batched(np.zeros((3, 7)), np.zeros((3, 11, 4)), np.full((3, 11), 8.0))

@@ -20,13 +20,17 @@ def _tol(u_ref, umax=0.9):
     return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
 
 
-@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("L", 10, 0.5), ("OFL", 50, 0.5), ("L", 64, 0.64)])
+# horizons 10..64 in steps the library instantiates run register-resident; 54, 80, 100 and 128 take the any-horizon kernel
+# (one and two stages per lane, and its largest size)
+@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("L", 10, 0.5), ("OFL", 50, 0.5), ("L", 64, 0.64),
+                                       ("L", 54, 0.54), ("OFL", 80, 0.8), ("L", 100, 1.0), ("L", 128, 1.28),
+                                       ("L", 7, 0.07)])
 def test_solve_only_matches_checker(orc80, kind, N, Tf):
     import torch
     from oracle import oracle as O
     from mpc_amd.controllers import LOcp, OFLOcp
     rng = np.random.default_rng(7)
-    B = 48
+    B = 48 if N <= 64 else 24
     st = _scenarios(rng, B)
     st[0] = [15.0, 0.1, 1, 0, 8.0, 0, 0, 0]
     st[1] = [15.0, -0.3, 1, 0, 8.0, 0, 0, 0.28]       # steering bound becomes active
@@ -57,19 +61,19 @@ def test_solve_only_matches_checker(orc80, kind, N, Tf):
             err = np.abs(U[b] - U_ref)
             assert (err <= _tol(U_ref)).all(), (cached, b, err.max(), iters[b])
             np.testing.assert_allclose(traj[b], traj_ref, rtol=1e-7, atol=1e-8)
-        assert nconstrained >= 8        # the active-bound branch was exercised
-        if kind == "L":
+        assert nconstrained >= 3        # the active-bound branch was exercised
+        if kind == "L" and Tf <= 0.55:   # longer previews reach the first circle, where bounds bite
             assert iters[3] == 0        # and so was the unconstrained shortcut
 
 
-@pytest.mark.parametrize("cached", [False, True])
-def test_closed_loop_steps_match_checker(orc80, cached):
+@pytest.mark.parametrize("cached,N,Tf", [(False, 50, 0.5), (True, 50, 0.5), (False, 72, 0.72)])
+def test_closed_loop_steps_match_checker(orc80, cached, N, Tf):
     """40 fused closed-loop steps (plan -> solve -> RK4 -> lap) against the checker's own loop."""
     import torch
     from oracle import oracle as O
     from mpc_amd.batched import SkidpadBatch
     rng = np.random.default_rng(11)
-    B, N, Tf, nsteps = 32, 50, 0.5, 40
+    B, nsteps = 32, 40
     st = _scenarios(rng, B)
     cfg = O.make_cfg("L", N, Tf)
     sim = SkidpadBatch(N, Tf, st, model="L", fixed_model_cache=cached)
@@ -86,12 +90,13 @@ def test_closed_loop_steps_match_checker(orc80, cached):
     assert (sim.lap.cpu().numpy() == laps).all()
 
 
-def test_fused_run_equals_step_by_step():
+@pytest.mark.parametrize("N,Tf", [(50, 0.5), (90, 0.9)])
+def test_fused_run_equals_step_by_step(N, Tf):
     """mpc_closed_loop_run (all steps in one launch) reproduces one-launch-per-step bit for bit."""
     import torch
     from mpc_amd.batched import SkidpadBatch
     rng = np.random.default_rng(5)
-    B, N, Tf, nsteps = 64, 50, 0.5, 60
+    B, nsteps = 64, 60
     st = _scenarios(rng, B)
     a = SkidpadBatch(N, Tf, st, model="L")
     b = SkidpadBatch(N, Tf, st, model="L")
