@@ -29,6 +29,7 @@ extern "C" {
 #define MPC_KIND_L 0      /* LMPC2.py   LOcp   */
 #define MPC_KIND_OFL 1    /* OFLMPC2.py OFLOcp */
 #define MPC_KIND_LPV 2    /* LPVMPC.py  LPVOcp */
+#define MPC_KIND_NL 3     /* NLMPC.py   NLOcp  (horizons 10, 20, 30, 40, 50, 64) */
 
 #define MPC_PLANNER_SKIDPAD 0 /* utils/path_planning.py SkidpadPlanner */
 #define MPC_PLANNER_STEP 1    /* utils/step_planning.py StepPlanner    */
@@ -53,6 +54,13 @@ typedef struct mpc_config {
     double tol_res;      /* interior-point stop: stationarity / feasibility residual           */
     int max_iter;        /* interior-point iteration cap                                      */
     int lpv_lin_prev;    /* LPV only: 0 = lin_mode "reference", 1 = "prev_iter" (LPVMPC.py:254) */
+    /* MPC_KIND_NL only (w, We, eps above are not read for it); NLMPC.py:159-186 hard-codes
+     * W = diag(0,1e5,1e-10,1,0,1,1 | 10), W_e = 100 * diag of the state part, and +0.1 in the tyre denominators */
+    double w_nl[8];      /* diag of W over [px,py,cos,sin,vy,r,delta | u]; stage cost is dt * 1/2 |y-yref|^2_W */
+    double we_nl[7];     /* diag of the terminal weight on the 7 states                        */
+    double eps_nl;       /* tyre-model denominator offset of the NL model (0.1)               */
+    double sqp_tol;      /* SQP stop: largest change of an input in one iteration             */
+    int sqp_max_iter;    /* SQP iteration cap per solve (status 1 when reached)               */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
@@ -80,7 +88,11 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
  *   x0      [B][7]  reduced state [pose(4), vy, r, delta]
  *   wp      [B][N+1][4] car-frame waypoints, p [B][N+1] speeds, d_hat [B] (OFL) or NULL
  *   lin_x   [B][6][N+1], lin_u [B][N]  LPV prev_x / prev_u, read and updated (NULL otherwise)
- *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B] (0 ok, 2 iteration cap), iters_out [B] */
+ *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B] (0 ok, 2 iteration cap), iters_out [B]
+ * MPC_KIND_NL (NLMPC.py:214-252): lin_u [B][N] is required and holds the SQP iterate, read as the starting point and
+ * updated with the solution, the way the reference's solver object keeps its iterate from call to call (zeros before
+ * the first call); lin_x is not used; traj_out rows are the 7 NL states [x, y, cos, sin, vy, r, delta]; status 1 =
+ * SQP iteration cap.  The closed-loop entry points below take lin_u the same way. */
 int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const double *wp, const double *p,
                    const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out,
                    int *status_out, int *iters_out);
@@ -139,7 +151,7 @@ int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, con
 /* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
  * copied to a host array of 16 doubles after synchronising the stream:
  *   [0] scenarios, [1] sum iterations, [2] count status != 0, [3] count constrained solves,
- *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual; rest reserved. */
+ *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual, [8] sum of SQP iterations (MPC_KIND_NL); rest reserved. */
 int mpc_get_stats(mpc_handle *h, void *stream, double *host16);
 
 #ifdef __cplusplus

@@ -9,9 +9,9 @@ import numpy as np
 
 from . import _build
 
-KIND = {"L": 0, "OFL": 1, "LPV": 2}
+KIND = {"L": 0, "OFL": 1, "LPV": 2, "NL": 3}
 PLANNER_SKIDPAD, PLANNER_STEP = 0, 1
-MAX_HORIZON = 64
+MAX_HORIZON = 128
 
 
 class MpcConfig(C.Structure):
@@ -20,6 +20,8 @@ class MpcConfig(C.Structure):
         ("dt", C.c_double), ("mp", C.c_double * 6), ("max_steering", C.c_double), ("max_rate", C.c_double),
         ("w", C.c_double * 7), ("We", C.c_double * 36), ("eps", C.c_double), ("tol_mu", C.c_double),
         ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
+        ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
+        ("sqp_max_iter", C.c_int),
     ]
 
 

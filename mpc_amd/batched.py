@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _dev, _lib
-from .controllers import LOcp, LPVOcp, OFLOcp
+from .controllers import LOcp, LPVOcp, NLOcp, OFLOcp
 from .EKF import P0_DIAG, Q_DIAG
 
 
@@ -27,8 +27,10 @@ class _ClosedLoopBatch:
             self.ocp = LOcp(N, Tf, batch=B, device=device, **ctl_kw)
         elif model == "LPV":
             self.ocp = LPVOcp(N, Tf, batch=B, device=device, **ctl_kw)
+        elif model == "NL":
+            self.ocp = NLOcp(N, Tf, batch=B, device=device, **ctl_kw)
         else:
-            raise ValueError("model must be 'L' or 'LPV' for the fused closed loop")
+            raise ValueError("model must be 'L', 'LPV' or 'NL' for the fused closed loop")
         self.MPC_controller = self.ocp
         dev = self.device = self.ocp.device
         self.state = _dev.f64(states, dev)
@@ -44,6 +46,8 @@ class _ClosedLoopBatch:
         if model == "LPV":
             self.lin_x = torch.zeros((B, 6, self.N + 1), dtype=torch.float64, device=dev)
             self.lin_u = torch.zeros((B, self.N), dtype=torch.float64, device=dev)
+        elif model == "NL":
+            self.lin_x, self.lin_u = None, self.ocp._iterate          # the SQP iterate travels from step to step
         else:
             self.lin_x = self.lin_u = None
         self.planned_references = None

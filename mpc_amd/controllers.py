@@ -76,7 +76,7 @@ class _CondensedMpc:
     n_outputs = 5
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
-                 batch: int = 1, tol_mu: float = 1e-13, tol_res: float = 1e-12, max_iter: int = 60,
+                 batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 60,
                  _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
@@ -227,6 +227,8 @@ class _CondensedMpc:
         self.metrics["runtime"].append(time.perf_counter() - t0)
         if st == 2:
             log.warning("interior-point iteration cap reached (status 2)")
+        elif st == 1 and self.kind == "NL":
+            log.warning("SQP iteration cap reached before the step tolerance (status 1)")
         elif st != 0:
             raise RuntimeError(f"MPC solve failed with status {st}")
         return 0, traj, U.reshape(self.N, 1)
@@ -243,8 +245,8 @@ class _CondensedMpc:
         rc = self.solver._lib.mpc_get_stats(self.solver.h, _dev.stream_ptr(self.device), _lib.hptr(out))
         _lib.check(rc, self.solver.h, "mpc_get_stats")
         keys = ["scenarios", "sum_iterations", "n_status_nonzero", "n_constrained", "sum_abs_u0", "max_abs_u0",
-                "max_complementarity", "max_residual"]
-        return dict(zip(keys, out[:8]))
+                "max_complementarity", "max_residual", "sum_sqp_iterations"]
+        return dict(zip(keys, out[:9]))
 
 
 class LOcp(_CondensedMpc):
@@ -315,3 +317,68 @@ class LPVOcp(_CondensedMpc):
         self.prev_x = lin_x.cpu().numpy()[0]
         self.prev_u = lin_u.cpu().numpy()
         return out
+
+
+class NLOcp(_CondensedMpc):
+    """Nonlinear MPC on the 7-state model [x, y, cos, sin, vy, r, delta] (NLMPC.py:9): Gauss-Newton SQP with the
+    explicit RK4 map of the reference's ERK integrator, solved to the step tolerance `sqp_tol` (at most
+    `sqp_max_iter` iterations per call).  The input iterate is kept between calls like the reference's solver object
+    keeps its own (NLMPC.py:232); `reset_iterate()` returns to the cold start."""
+
+    kind = "NL"
+    param_file = "parameters_NL.yaml"
+    n_states = 7
+    n_inputs = 1
+    n_outputs = 8
+
+    def __init__(self, N: int, Tf: float, debug: bool = False, *, sqp_tol: float = 1e-9, sqp_max_iter: int = 30, **kw):
+        self._sqp = (float(sqp_tol), int(sqp_max_iter))
+        super().__init__(N, Tf, True, debug, **kw)
+        self._iterate = None if self.device is None else torch.zeros((self.batch, self.N), dtype=torch.float64,
+                                                                     device=self.device)
+
+    def _cost_matrices(self):
+        Q = np.array([0, 1e5, 1e-10, 1e0, 0, 1e0, 1e0])                              # NLMPC.py:174-179
+        R = np.array([1e0]) * 10
+        return np.diag(np.append(Q, R)), np.diag(np.append(Q * 100, 0))
+
+    def _make_config(self) -> _lib.MpcConfig:
+        cfg = _lib.MpcConfig()
+        cfg.kind = _lib.KIND[self.kind]
+        cfg.N = self.N
+        cfg.B = self.batch
+        cfg.device = self.device.index if self.device is not None else 0
+        cfg.dt = self.dt
+        cfg.mp[:] = list(self.model_params())
+        cfg.max_steering = self.max_steering
+        cfg.max_rate = self.max_steering_rate
+        cfg.w_nl[:] = list(np.diag(self.W))
+        cfg.we_nl[:] = list(np.diag(self.W_e)[:7])
+        cfg.eps_nl = 0.1                                                             # NLMPC.py:116-126
+        cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
+        cfg.sqp_tol, cfg.sqp_max_iter = self._sqp
+        return cfg
+
+    def stability(self):
+        raise NotImplementedError("the reference's NLOcp has no terminal-set computation")
+
+    def condense_fixed(self, vx, exclusive: bool = False):
+        raise NotImplementedError("the NL model is re-linearised at every SQP iteration: nothing to cache")
+
+    def waypoints_to_references(self, waypoints: np.ndarray) -> np.ndarray:
+        references = np.zeros([self.N + 1, self.n_outputs])
+        references[:, :4] = waypoints[:, :]
+        return references
+
+    def reset_iterate(self):
+        self._iterate.zero_()
+
+    def solve_batched(self, x0, waypoints, p, d_hat=None, lin_x=None, lin_u=None, want_trajectory=True):
+        """Batched optimize(); `lin_u` (B,N) is the SQP iterate, read and updated in place (default: the iterate this
+        object keeps).  Returned trajectories hold the 7 NL states."""
+        if lin_u is None:
+            lin_u = self._iterate[: np.shape(x0)[0]]
+        return super().solve_batched(x0, waypoints, p, None, None, lin_u, want_trajectory)
+
+    def optimize(self, x0, waypoints, p):
+        return self._optimize_one(x0, waypoints, p)

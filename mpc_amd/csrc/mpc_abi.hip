@@ -10,6 +10,7 @@ struct mpc_handle {
     mpc_config cfg;
     mpc::DevCfg dev;
     double *Hws = nullptr;       // B * N * N condensed Hessians
+    int *sqp = nullptr;          // B SQP iteration counts of the last NL call
     double *stat = nullptr;      // B * 4 solver records
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     double *mp_scen = nullptr;   // optional B * 6
@@ -50,28 +51,35 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, MPC_EINVAL, "mpc_create: null argument");
     *out = nullptr;
-    if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_LPV) return fail(nullptr, MPC_EINVAL, "mpc_create: unknown kind");
+    if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_NL) return fail(nullptr, MPC_EINVAL, "mpc_create: unknown kind");
     if (!mpc::horizon_supported(cfg->N)) {
         char b[160];
         snprintf(b, sizeof b, "mpc_create: horizon N=%d is outside 2..%d", cfg->N, MPC_MAX_HORIZON);
         return fail(nullptr, MPC_EINVAL, b);
     }
     if (cfg->B < 1 || !(cfg->dt > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: need B >= 1 and dt > 0");
-    if (!(cfg->w[6] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight R*r must be positive (strict convexity)");
+    if (cfg->kind == MPC_KIND_NL) {
+        if (!mpc::horizon_templated(cfg->N)) return fail(nullptr, MPC_EINVAL, "mpc_create: the NL controller needs a horizon of 10, 20, 30, 40, 50 or 64");
+        if (!(cfg->w_nl[7] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight w_nl[7] must be positive (strict convexity)");
+    } else if (!(cfg->w[6] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight R*r must be positive (strict convexity)");
     mpc_handle *h = new (std::nothrow) mpc_handle();
     if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
     h->cfg = *cfg;
     mpc::DevCfg &d = h->dev;
     d.kind = cfg->kind; d.N = cfg->N; d.lpv_lin_prev = cfg->lpv_lin_prev; d.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 60;
     d.dt = cfg->dt; d.eps = cfg->eps; d.max_steering = cfg->max_steering; d.max_rate = cfg->max_rate;
-    d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-13; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
+    d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-15; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
     memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);
+    memcpy(d.w_nl, cfg->w_nl, sizeof d.w_nl); memcpy(d.we_nl, cfg->we_nl, sizeof d.we_nl);
+    d.eps_nl = cfg->eps_nl; d.sqp_tol = cfg->sqp_tol > 0 ? cfg->sqp_tol : 1e-9; d.sqp_max_iter = cfg->sqp_max_iter > 0 ? cfg->sqp_max_iter : 30;
     hipError_t e = hipSetDevice(cfg->device);
     const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
     if (e == hipSuccess) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "mpc_create: workspace allocation");
@@ -86,7 +94,7 @@ void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
-    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen);
+    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->sqp);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     delete h;
 }
@@ -104,7 +112,7 @@ int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
 int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
 {
     if (!h) return MPC_EINVAL;
-    if (h->cfg.kind == MPC_KIND_LPV) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV model is re-linearised every step");
+    if (h->cfg.kind == MPC_KIND_LPV || h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV and NL models are re-linearised every step");
     if (!(vx == vx)) { h->sh_on = false; return MPC_OK; }   // NaN switches the cache off
     // the cache belongs to the register-resident kernels; other horizons keep condensing per scenario (same results)
     if (!mpc::horizon_templated(h->cfg.N)) { h->sh_on = false; return MPC_OK; }
@@ -134,6 +142,12 @@ static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
     }
 }
 
+static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStream_t st)
+{
+    if (h->cfg.kind == MPC_KIND_NL) { a.sqp_out = h->sqp; return mpc::launch_mpc_nl(h->dev, a, st); }
+    return mpc::launch_mpc(h->dev, a, st);
+}
+
 static int check_batch(mpc_handle *h, int B, const char *who)
 {
     if (!h) return MPC_EINVAL;
@@ -148,6 +162,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     if (int rc = check_batch(h, B, "mpc_solve_only")) return rc;
     if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_solve_only: x0, wp, p and U_out are required");
     if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_solve_only: LPV needs lin_x and lin_u");
+    if (h->cfg.kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_solve_only: NL needs lin_u (the SQP iterate)");
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.U_out = U_out; a.traj_out = traj_out;
@@ -155,7 +170,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
-    HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
 
@@ -184,6 +199,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     if (!state || !target_vel || !u0_out) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: state, target_vel and u0_out are required");
     if (planner == MPC_PLANNER_SKIDPAD && (!lap || !prev_progress)) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: skidpad planner needs lap and prev_progress");
     if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: LPV needs lin_x and lin_u");
+    if (h->cfg.kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: NL needs lin_u (the SQP iterate)");
     if (h->cfg.kind == MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: the OFL loop runs on the estimate; use mpc_solve_only with the EKF entry points");
     mpc::SolveArgs a = {};
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
@@ -195,7 +211,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
-    HIP_TRY(h, mpc::launch_mpc(h->dev, a, (hipStream_t)stream));
+    HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
 
@@ -226,7 +242,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
 {
     if (!h || !host16) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
-    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->last_iters, h->last_status, h->stats16));
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->last_iters, h->last_status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->stats16));
     HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     return MPC_OK;

@@ -1,0 +1,178 @@
+// Register-resident Newton systems and the interior-point iteration of the condensed MPC problem (gfx950, wave64):
+// shared by the linear-model kernels (mpc_solver.hip) and the nonlinear SQP kernel (mpc_nl.hip).
+#pragma once
+#include "mpc_wave.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace mpc {
+
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Newton {
+    // Row `lane` of the symmetric Newton matrix.  After factor(): entries k < lane hold l(lane,k),
+    // entry lane holds d(lane), entries k > lane hold the frozen d(lane)*l(k,lane) (the transposed
+    // factor), so both triangular solves index registers statically.
+    double row[N];
+    double dinv;
+
+    __device__ __forceinline__ void factor(int lane)
+    {
+        dinv = 1.0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double c = row[k];                 // column k of the trailing matrix, one entry per lane
+            const double inv = fast_rcp(bcast(c, k));
+            const bool below = lane > k;
+            const double l = below ? c * inv : 0.0;
+            if (lane == k) dinv = inv;
+#pragma unroll
+            for (int j = k + 1; j < N; j++) {
+                row[j] = fma(-l, bcast(c, j), row[j]);
+                if (((j - k) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep readlane results (SGPRs) short-lived
+            }
+            if (below) row[k] = l;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // solves (L D L') x = b; b, x one entry per lane
+    __device__ __forceinline__ double solve(double b, int lane) const
+    {
+        double w = b;
+#pragma unroll
+        for (int k = 0; k < N - 1; k++) {
+            const double wk = bcast(w, k);
+            w = fma(-row[k], lane > k ? wk : 0.0, w);   // mask the broadcast value, not the row entry: a masked copy
+                                                        // of the row is loop-invariant and would be hoisted into 2N registers
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = N - 1; k > 0; k--) {
+            const double xk = bcast(w * dinv, k);
+            w = fma(-row[k], lane < k ? xk : 0.0, w);
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        return w * dinv;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Mehrotra predictor-corrector on  G U + t = h,  G = [A; -A],  A = [I; dt * prefix-sum].
+// H is read from memory (Hm[j*N + lane], symmetric); returns the solver status (0 converged, 2 iteration cap).
+//
+// Deliberately NOT inlined: it runs on the minority of steps whose unconstrained minimiser violates a bound, and
+// as a real call its ~250 registers (the Newton-matrix row alone is 2N) stay out of the register allocation of
+// the per-step hot path; the caller's live state is saved around the call only when the call happens.
+template <int N>
+__device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double xh5)
+{
+    Newton<N> nt;
+    double U, mu, res;
+    int iters;
+    const bool valid = lane < N, validd = lane < N - 1;
+    const double dt = prm.dt, dt2 = dt * dt;
+    const double umax = prm.umax, dmax = prm.dmax;
+    const double up_d = dmax - xh5, lo_d = -dmax - xh5;
+    const double gscale = fmax(1.0, wave_max(fabs(g)));
+    double tpu, tmu, lpu = 1.0, lmu = 1.0, tpd, tmd, lpd = 1.0, lmd = 1.0;
+    U = 0.0;
+    tpu = umax; tmu = umax;
+    tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax);
+    if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
+    if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
+    const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
+    double res_prev = 1e300;
+    int status = 0;
+    iters = 0;
+#pragma unroll 1
+    for (;;) {
+        // H is re-read from memory (L2-resident) wherever it is needed: laundering the pointer keeps the compiler
+        // from hoisting the N loads out of the iteration loop into 2N registers per lane.
+        const double *Hr = opaque_uniform(Hm);
+        double hu = 0.0;
+#pragma unroll 10
+        for (int j = 0; j < N; j++) hu = fma(valid ? Hr[j * N + lane] : 0.0, bcast(U, j), hu);
+        const double vd = dt * incl_prefix(U, lane);
+        const double lamd = validd ? (lpd - lmd) : 0.0;
+        double rd = hu + g + (lpu - lmu) + dt * incl_suffix(lamd, lane);
+        if (!valid) rd = 0.0;
+        const double rppu = valid ? U + tpu - umax : 0.0, rpmu = valid ? -U + tmu - umax : 0.0;
+        const double rppd = validd ? vd + tpd - up_d : 0.0, rpmd = validd ? -vd + tmd + lo_d : 0.0;
+        mu = wave_sum(tpu * lpu + tmu * lmu + tpd * lpd + tmd * lmd) * inv_nc;
+        const double resd = wave_max(fabs(rd));
+        const double resp = wave_max(fmax(fmax(fabs(rppu), fabs(rpmu)), fmax(fabs(rppd), fabs(rpmd))));
+        res = fmax(resd / gscale, resp);
+        // stop at the tolerances, or once the residual has reached the arithmetic's floor and stopped improving
+        if (mu <= prm.tol_mu && (res <= prm.tol_res || res >= 0.5 * res_prev)) break;
+        if (iters >= prm.max_iter) { status = 2; break; }
+        res_prev = res;
+        // Newton matrix  K = H + diag(Du) + dt^2 * Sfx[max(i,j)],  Sfx = suffix sums of Dd
+        const double Du = lpu / tpu + lmu / tmu;
+        const double Dd = validd ? lpd / tpd + lmd / tmd : 0.0;
+        const double sfx = incl_suffix(Dd, lane);
+        const double *Hk = opaque_uniform(Hm);
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const double sj = bcast(sfx, j);
+            double kij = valid ? Hk[j * N + lane] : 0.0;
+            kij = fma(dt2, (j > lane) ? sj : sfx, kij);
+            if (j == lane) kij += Du;
+            nt.row[j] = kij;
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
+        }
+        nt.factor(lane);
+        double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
+        double sigmu = 0.0, alpha = 1.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            double rcpu = tpu * lpu, rcmu = tmu * lmu, rcpd = tpd * lpd, rcmd = tmd * lmd;
+            if (pass) {
+                rcpu += dtpu * dlpu - sigmu; rcmu += dtmu * dlmu - sigmu;
+                rcpd += dtpd * dlpd - sigmu; rcmd += dtmd * dlmd - sigmu;
+            }
+            const double wu = (lpu * rppu - rcpu) / tpu - (lmu * rpmu - rcmu) / tmu;
+            const double wd = validd ? (lpd * rppd - rcpd) / tpd - (lmd * rpmd - rcmd) / tmd : 0.0;
+            double rhs = -rd - wu - dt * incl_suffix(wd, lane);
+            if (!valid) rhs = 0.0;
+            dU = nt.solve(rhs, lane);
+            if (!valid) dU = 0.0;
+            const double dvd = dt * incl_prefix(dU, lane);
+            dtpu = -rppu - dU; dtmu = -rpmu + dU;
+            dlpu = -(rcpu + lpu * dtpu) / tpu; dlmu = -(rcmu + lmu * dtmu) / tmu;
+            dtpd = -rppd - dvd; dtmd = -rpmd + dvd;
+            dlpd = -(rcpd + lpd * dtpd) / tpd; dlmd = -(rcmd + lmd * dtmd) / tmd;
+            if (!valid) { dtpu = 0; dtmu = 0; dlpu = 0; dlmu = 0; }
+            if (!validd) { dtpd = 0; dtmd = 0; dlpd = 0; dlmd = 0; }
+            double al = 1.0;
+            if (dtpu < 0) al = fmin(al, -tpu / dtpu);
+            if (dtmu < 0) al = fmin(al, -tmu / dtmu);
+            if (dlpu < 0) al = fmin(al, -lpu / dlpu);
+            if (dlmu < 0) al = fmin(al, -lmu / dlmu);
+            if (dtpd < 0) al = fmin(al, -tpd / dtpd);
+            if (dtmd < 0) al = fmin(al, -tmd / dtmd);
+            if (dlpd < 0) al = fmin(al, -lpd / dlpd);
+            if (dlmd < 0) al = fmin(al, -lmd / dlmd);
+            alpha = wave_min(al);
+            if (pass == 0) {
+                const double mua = wave_sum((tpu + alpha * dtpu) * (lpu + alpha * dlpu) +
+                                            (tmu + alpha * dtmu) * (lmu + alpha * dlmu) +
+                                            (tpd + alpha * dtpd) * (lpd + alpha * dlpd) +
+                                            (tmd + alpha * dtmd) * (lmd + alpha * dlmd)) * inv_nc;
+                const double sg = mua / mu;
+                sigmu = sg * sg * sg * mu;
+            }
+        }
+        alpha *= 0.995;
+        U = fma(alpha, dU, U);
+        tpu = fma(alpha, dtpu, tpu); tmu = fma(alpha, dtmu, tmu);
+        lpu = fma(alpha, dlpu, lpu); lmu = fma(alpha, dlmu, lmu);
+        tpd = fma(alpha, dtpd, tpd); tmd = fma(alpha, dtmd, tmd);
+        lpd = fma(alpha, dlpd, lpd); lmd = fma(alpha, dlmd, lmd);
+        iters++;
+    }
+    IpmResult out = {U, mu, res, iters, status};
+    return out;
+}
+
+}  // namespace mpc

@@ -19,6 +19,9 @@ struct DevCfg {
     double mp[6];
     double w[7];
     double We[36];
+    // nonlinear controller (MPC_KIND_NL) only
+    double w_nl[8], we_nl[7], eps_nl, sqp_tol;
+    int sqp_max_iter;
 };
 
 struct SolveArgs {
@@ -37,6 +40,7 @@ struct SolveArgs {
     double *Hws;                                          // workspace: B * N * N condensed Hessians
     double *U_out, *traj_out, *u0_out, *wp_out;
     int *status_out, *iters_out;
+    int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)
     double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
     // Fixed-model cache (every scenario at speed sh_vx with the handle's model parameters); NULL = off.
     const double *sh_H;      // [N][N] condensed Hessian
@@ -48,6 +52,7 @@ struct SolveArgs {
 };
 
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
+hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);    // MPC_KIND_NL, horizons of MPC_HORIZONS
 hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);   // run-time horizon, no cache
 hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
 bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
@@ -64,6 +69,7 @@ hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const do
                                double *prev_progress, const double *target_vel, double *wp_out, double *progress_out);
 hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
                             double *wp_out, double *progress_out, double *abs_out);
-hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, double *out16);
+hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
+                        double *out16);
 
 }  // namespace mpc

@@ -1,0 +1,412 @@
+// Nonlinear MPC step (NLMPC.py) as a wave-per-scenario Gauss-Newton SQP for gfx950.
+//
+// States [px, py, cos, sin, vy, r, delta], input u = steering rate, stage parameter vx.  One wavefront owns one
+// scenario and lane k owns stage k.  The decision variables are the inputs alone (single shooting): per SQP iteration
+//   1. the state trajectory is rolled out with the explicit RK4 map (NLMPC.py:196, one step per interval),
+//   2. lane k differentiates that map at (x_k, u_k): A_k = d x_{k+1} / d x_k, b_k = d x_{k+1} / d u_k,
+//   3. the LINEAR_LS cost (NLMPC.py:159-186) is condensed into H = Gamma' W Gamma + R and the gradient g,
+//   4. the QP in the new inputs, min 1/2 U'HU + (g - H U_cur)'U subject to |u_k| <= max_rate and
+//      |delta_0 + dt sum_{j<=k} u_j| <= max_steering (the steering bound stays exactly linear in U), is solved like the
+//      linear controllers' QP: unconstrained minimiser first, interior point if a bound is violated,
+//   5. the full step is taken; the iteration stops when the step falls below the tolerance.
+// The input iterate is kept between calls, as the reference's solver object keeps its iterate (NLMPC.py:232).
+#include "mpc_ipm.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace mpc {
+
+constexpr int NL_STAGE_W = 42;   // A[7][5] (columns cos, sin, vy, r, delta; the px and py columns are unit vectors) + b[7]
+
+struct NlCoef { double vx, a11, a12, a21, a22, b1, b2; };
+
+// NLMPC.py:108-134
+__device__ __forceinline__ void nl_f(const double *x, double u, const NlCoef &c, double *xd)
+{
+    xd[0] = c.vx * x[2] - x[4] * x[3];
+    xd[1] = c.vx * x[3] + x[4] * x[2];
+    xd[2] = -x[3] * x[5];
+    xd[3] = x[2] * x[5];
+    xd[4] = c.a11 * x[4] + c.a12 * x[5] + c.b1 * x[6];
+    xd[5] = c.a21 * x[4] + c.a22 * x[5] + c.b2 * x[6];
+    xd[6] = u;
+}
+
+__device__ __forceinline__ void nl_rk4(double *x, double u, double h, const NlCoef &c)
+{
+    double k1[7], k2[7], k3[7], k4[7], t[7];
+    nl_f(x, u, c, k1);
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = fma(0.5 * h, k1[i], x[i]);
+    nl_f(t, u, c, k2);
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = fma(0.5 * h, k2[i], x[i]);
+    nl_f(t, u, c, k3);
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = fma(h, k3[i], x[i]);
+    nl_f(t, u, c, k4);
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = fma(h / 6.0, k1[i] + 2.0 * (k2[i] + k3[i]) + k4[i], x[i]);
+}
+
+// r = (d f / d x)(xs) v, rows 0..5 (row 6 of the Jacobian is zero); xs4 = [cos, sin, vy, r] of the evaluation point
+__device__ __forceinline__ void nl_jv(const double *xs4, const NlCoef &c, const double *v, double *r)
+{
+    const double co = xs4[0], si = xs4[1], vy = xs4[2], rr = xs4[3];
+    r[0] = c.vx * v[2] - vy * v[3] - si * v[4];
+    r[1] = vy * v[2] + c.vx * v[3] + co * v[4];
+    r[2] = -rr * v[3] - si * v[5];
+    r[3] = rr * v[2] + co * v[5];
+    r[4] = c.a11 * v[4] + c.a12 * v[5] + c.b1 * v[6];
+    r[5] = c.a21 * v[4] + c.a22 * v[5] + c.b2 * v[6];
+}
+
+// Exact derivative of the RK4 map at (x, u): st[r*5 + (c-2)] = d xn[r] / d x[c] for c = 2..6, st[35 + r] = d xn[r] / d u.
+__device__ __forceinline__ void nl_linearise(const double *x, double u, double h, const NlCoef &c, double *st)
+{
+    double xs[4][4];
+    {
+        double k[7], t[7];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xs[0][i] = x[2 + i];
+        nl_f(x, u, c, k);
+#pragma unroll
+        for (int i = 0; i < 7; i++) t[i] = fma(0.5 * h, k[i], x[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) xs[1][i] = t[2 + i];
+        nl_f(t, u, c, k);
+#pragma unroll
+        for (int i = 0; i < 7; i++) t[i] = fma(0.5 * h, k[i], x[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) xs[2][i] = t[2 + i];
+        nl_f(t, u, c, k);
+#pragma unroll
+        for (int i = 0; i < 7; i++) t[i] = fma(h, k[i], x[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) xs[3][i] = t[2 + i];
+    }
+#pragma unroll
+    for (int sd = 0; sd < 6; sd++) {        // seeds: states 2..6, then the input
+        const double du = (sd == 5) ? 1.0 : 0.0;
+        double e[7] = {0, 0, 0, 0, 0, 0, 0}, K[6], acc[6], t[7];
+        if (sd < 5) e[2 + sd] = 1.0;
+        nl_jv(xs[0], c, e, K);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { acc[i] = K[i]; t[i] = fma(0.5 * h, K[i], e[i]); }
+        t[6] = fma(0.5 * h, du, e[6]);
+        nl_jv(xs[1], c, t, K);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { acc[i] = fma(2.0, K[i], acc[i]); t[i] = fma(0.5 * h, K[i], e[i]); }
+        nl_jv(xs[2], c, t, K);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { acc[i] = fma(2.0, K[i], acc[i]); t[i] = fma(h, K[i], e[i]); }
+        t[6] = fma(h, du, e[6]);
+        nl_jv(xs[3], c, t, K);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double col = fma(h / 6.0, acc[i] + K[i], e[i]);
+            if (sd < 5) st[i * 5 + sd] = col;
+            else st[35 + i] = col;
+        }
+        if (sd < 5) st[6 * 5 + sd] = e[6];
+        else st[35 + 6] = h;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const SolveArgs a)
+{
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    const bool valid = lane < N, validd = lane < N - 1;
+    extern __shared__ double lds[];
+    double *s_ref = lds;                              // [4][N+1]: x, y, cos, sin of the car-frame waypoints
+    double *s_p = s_ref + 4 * (N + 1);                // [N+1] speeds
+    double *s_coef = s_p + (N + 1);                   // [N][4]: a11, a12, a21, a22 per stage
+    double *s_x = s_coef + 4 * N;                     // [N+1][7] rolled-out states
+    double *s_stage = s_x + 7 * (N + 1);              // [N][NL_STAGE_W]
+    double *s_wv = s_stage + N * NL_STAGE_W;          // [7][N] weighted prediction columns
+
+    ModelParams mp;
+    if (a.mp_scen) {
+        const double *q = a.mp_scen + 6 * (size_t)s;
+        mp = {q[0], q[1], q[2], q[3], q[4], q[5]};
+    } else
+        mp = {cfg.mp[0], cfg.mp[1], cfg.mp[2], cfg.mp[3], cfg.mp[4], cfg.mp[5]};
+    const double dt = cfg.dt;
+    const double umax = cfg.max_rate, dmax = cfg.max_steering;
+    const double b1 = -mp.Cf / mp.m, b2 = -mp.lf * mp.Cf / mp.Iz;
+    double wq[7], wN[7];
+#pragma unroll
+    for (int c = 0; c < 7; c++) { wq[c] = dt * cfg.w_nl[c]; wN[c] = cfg.we_nl[c]; }   // stage costs carry the time step
+    const double wr = dt * cfg.w_nl[7];
+
+    double plant[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double prevp = 0.0, tvel = 0.0;
+    int lapv = 0;
+    if (a.mode != MODE_SOLVE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) plant[i] = a.state[(size_t)8 * s + i];
+        tvel = a.target_vel[s];
+        if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
+    }
+    double U = valid ? a.lin_u[(size_t)s * N + lane] : 0.0;    // SQP iterate, carried from call to call
+    const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
+    int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0;
+    double mu = 0.0, res = 0.0, u0 = 0.0;
+    double *Hw = a.Hws + (size_t)s * N * N;
+
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t++) {
+        // ------------------------------------------------------------ 1. start state and references
+        double xh[7] = {0, 0, 1, 0, 0, 0, 0};                           // NLMPC.py:216
+        if (a.mode == MODE_SOLVE) {
+            const double *x0 = a.x0 + 7 * (size_t)s;
+            xh[4] = x0[4]; xh[5] = x0[5]; xh[6] = x0[6];
+            for (int k = lane; k <= N; k += WAVE) {
+                const double *w = a.wp + ((size_t)s * (N + 1) + k) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_ref[c * (N + 1) + k] = w[c];   // NLMPC.py:208-212
+                s_p[k] = a.p[(size_t)s * (N + 1) + k];
+            }
+        } else {
+            const double px = plant[0], py = plant[1];
+            xh[4] = plant[5]; xh[5] = plant[6]; xh[6] = plant[7];
+            const double heading = atan2(plant[3], plant[2]);
+            double p0;
+            if (a.mode == MODE_SKIDPAD) {
+                int lp = lapv;
+                p0 = sk_pos2progress(px, py, lp);
+                if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
+                prevp = p0;
+            } else
+                p0 = px;
+            const double ch = cos(heading), sh = sin(heading);
+            for (int k = lane; k <= N; k += WAVE) {
+                double o[4];
+                const double q = waypoint_progress(p0, tvel, dt, k);
+                if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
+                else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+                to_car_frame(o, px, py, ch, sh);
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_ref[c * (N + 1) + k] = o[c];
+                s_p[k] = tvel;
+                if (a.wp_out) {
+                    double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
+                    w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+                }
+            }
+        }
+        wave_sync();
+        NlCoef cl;          // this lane's stage
+        cl.vx = s_p[valid ? lane : 0];
+        {
+            double a11, a12, a21, a22;
+            lat_coeffs(mp, cl.vx, cfg.eps_nl, a11, a12, a21, a22);      // NLMPC.py:116-128
+            cl.a11 = a11; cl.a12 = a12; cl.a21 = a21; cl.a22 = a22; cl.b1 = b1; cl.b2 = b2;
+            if (valid) { s_coef[lane * 4] = a11; s_coef[lane * 4 + 1] = a12; s_coef[lane * 4 + 2] = a21; s_coef[lane * 4 + 3] = a22; }
+        }
+        wave_sync();
+        const double up_d = dmax - xh[6], lo_d = -dmax - xh[6];
+
+        // ------------------------------------------------------------ 2. SQP iterations
+        int iters = 0, status = 1, sqp = 0;
+        double keep[7], step_prev = 1e300;
+#pragma unroll 1
+        for (;;) {
+            const bool last = (status == 0) || (sqp >= cfg.sqp_max_iter);
+            if (last && !a.traj_out) break;
+            // 2a. roll the trajectory out; lane k keeps x_k, every lane ends with x_N
+            double x[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { x[i] = xh[i]; keep[i] = xh[i]; }
+#pragma unroll 1
+            for (int k = 0; k < N; k++) {
+                NlCoef ck;
+                ck.vx = s_p[k]; ck.a11 = s_coef[k * 4]; ck.a12 = s_coef[k * 4 + 1]; ck.a21 = s_coef[k * 4 + 2];
+                ck.a22 = s_coef[k * 4 + 3]; ck.b1 = b1; ck.b2 = b2;
+                nl_rk4(x, bcast(U, k), dt, ck);
+                if (lane == k + 1) {
+#pragma unroll
+                    for (int i = 0; i < 7; i++) keep[i] = x[i];
+                }
+            }
+            if (last) {                       // the pass after the final step only produces the prediction
+                if (valid) {
+                    double *o = a.traj_out + ((size_t)s * (N + 1) + lane) * 7;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) o[i] = keep[i];
+                }
+                if (lane == 0) {
+                    double *o = a.traj_out + ((size_t)s * (N + 1) + N) * 7;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) o[i] = x[i];
+                }
+                break;
+            }
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) s_x[lane * 7 + i] = keep[i];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) s_x[N * 7 + i] = x[i];
+            }
+            // 2b. derivative of the RK4 map per stage
+            if (valid) nl_linearise(keep, U, dt, cl, &s_stage[lane * NL_STAGE_W]);
+            wave_sync();
+
+            // 2c. condense: lane j carries v = d x_k / d u_j
+            Newton<N> nt;
+            double g = 0.0;
+            {
+#pragma unroll
+                for (int i = 0; i < N; i++) nt.row[i] = 0.0;
+                double v[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+                for (int k = 1; k <= N; k++) {
+                    const double *st = &s_stage[(k - 1) * NL_STAGE_W];
+                    {
+                        double n[6];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            double acc = (r < 2) ? v[r] : 0.0;
+#pragma unroll
+                            for (int c = 0; c < 5; c++) acc = fma(st[r * 5 + c], v[2 + c], acc);
+                            n[r] = acc;
+                        }
+#pragma unroll
+                        for (int r = 4; r < 6; r++) {      // vy and r depend on vy, r, delta only
+                            double acc = 0.0;
+#pragma unroll
+                            for (int c = 2; c < 5; c++) acc = fma(st[r * 5 + c], v[2 + c], acc);
+                            n[r] = acc;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; r++) v[r] = n[r];
+                        if (lane == k - 1) {
+#pragma unroll
+                            for (int r = 0; r < 7; r++) v[r] = st[35 + r];
+                        }
+                    }
+                    double wv[7];
+#pragma unroll
+                    for (int c = 0; c < 7; c++) wv[c] = (k < N ? wq[c] : wN[c]) * v[c];
+                    const double *xk = &s_x[k * 7];
+#pragma unroll
+                    for (int c = 0; c < 7; c++) {
+                        const double err = (c < 4) ? xk[c] - s_ref[c * (N + 1) + k] : xk[c];
+                        g = fma(wv[c], err, g);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int c = 0; c < 7; c++) s_wv[c * N + lane] = wv[c];
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int c = 0; c < 7; c++) {
+                        if ((k < N ? wq[c] : wN[c]) != 0.0) {
+                            const double vc = v[c];
+#pragma unroll
+                            for (int i = 0; i < N; i++) nt.row[i] = fma(s_wv[c * N + i], vc, nt.row[i]);
+                        }
+                    }
+                    wave_sync();
+                }
+            }
+            // 2d. QP in the new inputs: gradient g + wr U - (H U) with H = Gamma' W Gamma + wr I
+            double hu = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                hu = fma(nt.row[j], bcast(U, j), hu);
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            double gq = valid ? g - hu : 0.0;        // (g + wr U) - (Gamma'W Gamma U + wr U)
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if (i == lane) nt.row[i] += wr;
+                if (valid) Hw[i * N + lane] = nt.row[i];
+            }
+            nt.factor(lane);
+            double Un = valid ? nt.solve(-gq, lane) : 0.0;
+            const double vd = dt * incl_prefix(Un, lane);
+            bool ok = fabs(Un) <= umax;
+            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+            if (!__all(ok)) {
+                nconstr++;
+                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
+                const IpmResult r = interior_point<N>(prm, lane, Hw, gq, xh[6]);
+                Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
+                if (r.status) status_max = max(status_max, r.status);
+            }
+            const double step = wave_max(valid ? fabs(Un - U) : 0.0);
+            U = valid ? Un : 0.0;
+            sqp++;
+            // converged: step below the tolerance, or within 1000x of it and no longer shrinking (the floor set by the
+            // accuracy of the QP solutions has been reached)
+            if (step <= cfg.sqp_tol || (step <= 1e3 * cfg.sqp_tol && step >= 0.5 * step_prev)) status = 0;
+            step_prev = step;
+        }
+        sqp_tot += sqp;
+        iters_tot += iters;
+        status_max = max(status_max, status);
+
+        // ------------------------------------------------------------ 3. outputs and plant
+        if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;
+        u0 = bcast(U, 0);
+        if (a.mode != MODE_SOLVE) {
+            const double oldx = plant[0];
+            plant_rk4<10>(plant, u0, dt, mp);
+            if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
+            if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
+            if (a.x_hist && lane < 8) {
+                double val = plant[0];
+#pragma unroll
+                for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
+                a.x_hist[((size_t)t * a.B + s) * 8 + lane] = val;
+            }
+        }
+        wave_sync();
+    }
+
+    if (valid) a.lin_u[(size_t)s * N + lane] = U;
+    if (a.mode != MODE_SOLVE) {
+        if (lane < 8) {
+            double val = plant[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++) val = (lane == i) ? plant[i] : val;
+            a.state[(size_t)8 * s + lane] = val;
+        }
+        if (a.mode == MODE_SKIDPAD && lane == 0) { a.lap[s] = lapv; a.prev_progress[s] = prevp; }
+    }
+    if (lane == 0) {
+        if (a.u0_out) a.u0_out[s] = u0;
+        if (a.status_out) a.status_out[s] = status_max;
+        if (a.iters_out) a.iters_out[s] = iters_tot;
+        if (a.sqp_out) a.sqp_out[s] = sqp_tot;
+        if (a.stat_out) {
+            double *so = a.stat_out + 4 * (size_t)s;
+            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+        }
+    }
+}
+
+template <int N>
+static hipError_t launch_nl_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (size_t)(4 * (N + 1) + (N + 1) + 4 * N + 7 * (N + 1) + N * NL_STAGE_W + 7 * N);
+    hipLaunchKernelGGL(k_mpc_nl<N>, dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
+{
+    switch (cfg.N) {
+#define MPC_CASE(n) case n: return launch_nl_n<n>(cfg, a, st);
+        MPC_HORIZONS(MPC_CASE)
+#undef MPC_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mpc

@@ -20,8 +20,8 @@ import yaml
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
-KIND = {"L": 0, "OFL": 1, "LPV": 2}
-CFG_LEN = 56
+KIND = {"L": 0, "OFL": 1, "LPV": 2, "NL": 3}
+CFG_LEN = 74
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -59,6 +59,8 @@ class Oracle:
         L.orc_mpc_optimize.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                        C.c_double, C.c_int]
         L.orc_mpc_optimize.restype = C.c_int
+        L.orc_nl_optimize.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int]
+        L.orc_nl_optimize.restype = C.c_int
         L.orc_skidpad_step.argtypes = [_dp, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
                                        C.c_int]
         L.orc_skidpad_step.restype = C.c_int
@@ -130,6 +132,19 @@ class Oracle:
                                        _ptr(lin_u), _ptr(traj), _ptr(U), _ptr(lam), _ptr(info), tol[0], tol[1], tol[2])
         return st, traj, U, lam, info
 
+    def nl_optimize(self, cfg, x0_7, wp, p, U_warm=None, tol=None):
+        """NLOcp.optimize; U_warm is the iterate kept from the previous call (None = zeros).  Returns
+        (status, traj (N+1,7), U (N,), lam (2N,), info [qp iterations, sqp iterations, last step, defect])."""
+        N = int(cfg[1])
+        traj = np.zeros((N + 1, 7)); lam = np.zeros(2 * N); info = np.zeros(4)
+        U = np.zeros(N) if U_warm is None else np.array(U_warm, dtype=np.float64).reshape(N)
+        tol = tol or self.tol
+        st = self.lib.orc_nl_optimize(_ptr(cfg), _ptr(np.ascontiguousarray(x0_7, dtype=np.float64)),
+                                      _ptr(np.ascontiguousarray(wp, dtype=np.float64)),
+                                      _ptr(np.ascontiguousarray(p, dtype=np.float64)), _ptr(U), _ptr(traj), _ptr(lam),
+                                      _ptr(info), tol[0], tol[1], tol[2])
+        return st, traj, U, lam, info
+
     def skidpad_step(self, cfg, state8, lap, prev_progress, target_vel, lin_x=None, lin_u=None, tol=None):
         tol = tol or self.tol
         st8 = np.array(state8, dtype=np.float64); lp = C.c_int(int(lap)); pp = np.array([prev_progress], dtype=np.float64)
@@ -156,7 +171,8 @@ _DEFAULT_CFG_DIR = os.path.join(os.path.dirname(_HERE), "mpc_amd", "config")
 
 
 def load_params(kind: str, path: str | None = None) -> dict:
-    name = {"L": "parameters_L.yaml", "OFL": "parameters_L.yaml", "LPV": "parameters_LPV.yaml"}[kind]
+    name = {"L": "parameters_L.yaml", "OFL": "parameters_L.yaml", "LPV": "parameters_LPV.yaml",
+            "NL": "parameters_NL.yaml"}[kind]
     with open(path or os.path.join(_DEFAULT_CFG_DIR, name)) as fh:
         return yaml.safe_load(fh)
 
@@ -197,10 +213,19 @@ def dare_terminal(mp, dt, W):
 
 
 def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Oracle | None = None,
-             lin_mode: str = "reference") -> np.ndarray:
+             lin_mode: str = "reference", sqp_tol: float = 1e-11, sqp_max_iter: int = 50) -> np.ndarray:
     params = params or load_params(kind)
     mp = model_params(params, orc)
     dt = Tf / N
+    if kind == "NL":
+        # NLMPC.py:159-186: weights are hard-coded (the yaml's controller block is not read), W_e = 100 Q
+        Q = np.array([0, 1e5, 1e-10, 1e0, 0, 1e0, 1e0])
+        cfg = np.zeros(CFG_LEN)
+        cfg[0] = KIND[kind]; cfg[1] = N; cfg[2] = dt; cfg[3:9] = mp
+        cfg[9] = params["model"]["max_steering_angle"]; cfg[10] = params["model"]["max_steering_rate"]
+        cfg[56:63] = Q; cfg[63] = 10.0; cfg[64:71] = 100 * Q; cfg[71] = 0.1
+        cfg[72] = sqp_tol; cfg[73] = sqp_max_iter
+        return cfg
     c = params["controller"]
     W = np.zeros((7, 7))
     W[:6, :6] = np.array(c["Q"], dtype=np.float64) * c["q"]

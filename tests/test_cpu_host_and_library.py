@@ -37,12 +37,23 @@ def test_ctypes_binding_covers_the_header(lib_path):
     _lib.load()                                   # sets argtypes on every symbol; raises if one is missing
 
 
-def test_config_struct_matches_header_layout():
+def test_config_struct_matches_header_layout(tmp_path):
+    """The ctypes mirror against the C compiler's layout of struct mpc_config in include/mpc_amd.h, field by field."""
+    import subprocess
     from mpc_amd import _lib
     c = _lib.MpcConfig
-    # ints 4*4, dt 8, mp 48, two bounds 16, w 56, We 288, eps/tol_mu/tol_res 24, two ints 8
-    assert ctypes.sizeof(c) == 16 + 8 + 48 + 16 + 56 + 288 + 24 + 8
-    assert c.dt.offset == 16 and c.w.offset == 16 + 8 + 48 + 16 and c.max_iter.offset == ctypes.sizeof(c) - 8
+    names = [f[0] for f in c._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpc_amd.h"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(mpc_config));']
+    lines += [f'  printf("%zu\\n", offsetof(mpc_config, {n}));' for n in names]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert ctypes.sizeof(c) == out[0]
+    assert [getattr(c, n).offset for n in names] == out[1:]
 
 
 @pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("OFL", 50, 1.0), ("LPV", 80, 0.8), ("L", 10, 0.5)])

@@ -1,0 +1,116 @@
+"""GPU parity of the nonlinear controller (NLOcp, NLMPC.py) against the CPU checker.
+
+The checker iterates on states and inputs (multiple shooting, stage-wise Riccati interior point, 80-bit arithmetic);
+the library iterates on the inputs alone (single shooting, condensed).  Both are Gauss-Newton SQP methods on the same
+nonlinear programme and are driven to a step below 1e-11 (checker) / 1e-10 (library), so they must agree on the local minimiser they reach from the
+same start.  Bar: |u_gpu - u_ref| <= 1e-5 * max(|u_ref|, 1e-3 * u_max) per input, as for the linear controllers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(u_ref, umax=0.9):
+    return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
+
+
+def _scenarios(rng, B, vx=8.0):
+    psi = rng.uniform(-0.1, 0.1, B)
+    return np.stack([np.full(B, 15.0), rng.uniform(-0.3, 0.3, B), np.cos(psi), np.sin(psi), np.full(B, vx),
+                     rng.uniform(-0.2, 0.2, B), rng.uniform(-0.2, 0.2, B), rng.uniform(-0.05, 0.05, B)], axis=1)
+
+
+@pytest.mark.parametrize("N,Tf", [(50, 0.5), (20, 0.4)])
+def test_nl_solve_matches_checker_cold_and_warm(orc80, N, Tf):
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.controllers import NLOcp
+    rng = np.random.default_rng(21)
+    B = 24
+    st = _scenarios(rng, B)
+    st[0] = [15.0, 0.1, 1, 0, 8.0, 0, 0, 0]
+    st[1] = [12.0, 0.0, 1, 0, 8.0, 0, 0, 0.0]           # on the line: no bound active
+    st[2] = [15.0, 0.3, 1, 0, 8.0, 0, 0, 0.28]          # steering bound active
+    cfg = O.make_cfg("NL", N, Tf, sqp_tol=1e-11, sqp_max_iter=50)
+    ctl = NLOcp(N, Tf, batch=B, sqp_tol=1e-10, sqp_max_iter=50)
+    x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]
+    warm = [None] * B
+    for call in range(2):                                # second call: moved scenario, iterate carried over
+        wps, ps = [], []
+        for s in st:
+            wp, sp, _, _ = orc80.skidpad_waypoints(s[0], s[1], np.arctan2(s[3], s[2]), 0, 0.0, s[4], N, Tf / N)
+            wps.append(wp); ps.append(sp)
+        wps = np.array(wps); ps = np.array(ps)
+        U, traj, status, iters = ctl.solve_batched(x0, wps, ps)
+        torch.cuda.synchronize()
+        U = U.cpu().numpy(); traj = traj.cpu().numpy(); status = status.cpu().numpy()
+        assert (status == 0).all(), status
+        nactive = 0
+        for b in range(B):
+            stt, traj_ref, U_ref, lam, info = orc80.nl_optimize(cfg, x0[b], wps[b], ps[b], warm[b])
+            assert stt == 0, (b, info)
+            warm[b] = U_ref
+            nactive += int(np.abs(lam).max() > 1e-9)
+            err = np.abs(U[b] - U_ref)
+            assert (err <= _tol(U_ref)).all(), (call, b, err.max())
+            np.testing.assert_allclose(traj[b], traj_ref, rtol=1e-7, atol=1e-8)
+        assert nactive >= 3
+        np.testing.assert_array_equal(ctl._iterate.cpu().numpy(), U)      # the iterate is kept for the next call
+        sqp = ctl.stats()["sum_sqp_iterations"]
+        assert B <= sqp <= 50 * B
+        # next call: every scenario advanced by one plant step with its own first input
+        for b in range(B):
+            st[b] = orc80.plant_rk4(st[b], warm[b][0], Tf / N, cfg[3:9])
+        x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]
+
+
+def test_nl_closed_loop_matches_checker(orc80):
+    """30 fused closed-loop skidpad steps (plan -> SQP -> RK4 plant -> lap) with the iterate carried from step to step."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    rng = np.random.default_rng(22)
+    B, N, Tf, nsteps = 16, 50, 0.5, 30
+    st = _scenarios(rng, B)
+    cfg = O.make_cfg("NL", N, Tf, sqp_tol=1e-11, sqp_max_iter=50)
+    ref_states = st.copy(); laps = np.zeros(B, np.int32); pp = np.zeros(B)
+    uh_ref, _ = orc80.skidpad_run(cfg, ref_states, laps, pp, 8.0, nsteps)
+    a = SkidpadBatch(N, Tf, st, model="NL", sqp_tol=1e-10, sqp_max_iter=50)
+    xs, us = a.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    us = us.cpu().numpy()
+    assert (a.status.cpu().numpy() == 0).all()
+    assert (np.abs(us - uh_ref) <= 10 * _tol(uh_ref)).all(), np.abs(us - uh_ref).max()
+    np.testing.assert_allclose(a.state.cpu().numpy(), ref_states, rtol=0, atol=1e-7)
+    # one launch per step gives the same numbers as the fused run
+    b = SkidpadBatch(N, Tf, st, model="NL", sqp_tol=1e-10, sqp_max_iter=50)
+    us_b = torch.stack([b.step().clone() for _ in range(nsteps)])
+    assert torch.equal(us_b.cpu(), torch.from_numpy(us))
+
+
+def test_nl_simulators_and_iteration_cap(orc64):
+    """SkidpadSimulator / StepSimulator with model="NL" (skidpad_simulator.py:37-39, simulator.py:70-72) and the
+    fixed-iteration mode (status 1 flags an iterate that has not met the step tolerance)."""
+    from oracle import oracle as O
+    from mpc_amd.skidpad_simulator import SkidpadSimulator
+    from mpc_amd.controllers import NLOcp
+    N, Tf = 50, 0.5
+    sim = SkidpadSimulator(N, Tf, model="NL")
+    cfg = O.make_cfg("NL", N, Tf, sqp_tol=1e-9, sqp_max_iter=30)
+    x = sim.full_state.copy(); lap = 0; pp = 0.0; warm = None
+    for i in range(5):
+        hd = np.arctan2(x[3], x[2])
+        wp, sp, p0, pp = orc64.skidpad_waypoints(x[0], x[1], hd, lap, pp, 8.0, N, Tf / N)
+        stt, traj, U, lam, info = orc64.nl_optimize(cfg, x[[0, 1, 2, 3, 5, 6, 7]], wp, sp, warm)
+        warm = U
+        sim.step()
+        assert sim.planned_trajectory.shape == (N + 1, 7)
+        x = orc64.plant_rk4(x, U[0], Tf / N, cfg[3:9])
+        np.testing.assert_allclose(sim.full_state, x, rtol=0, atol=1e-7)
+    ctl = NLOcp(N, Tf, sqp_max_iter=1)
+    wp, sp, _, _ = orc64.skidpad_waypoints(15.0, 0.3, 0.0, 0, 0.0, 8.0, N, Tf / N)
+    status, traj, inputs = ctl.optimize(np.array([15.0, 0.3, 1, 0, 0, 0, 0.0]), wp, sp)
+    assert status == 0 and inputs.shape == (N, 1) and traj.shape == (N + 1, 7)
+    assert ctl.stats()["n_status_nonzero"] == 1 and ctl.stats()["sum_sqp_iterations"] == 1
+    with pytest.raises(RuntimeError, match="horizon"):
+        NLOcp(54, 0.54)
