@@ -88,7 +88,10 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
  *   x0      [B][7]  reduced state [pose(4), vy, r, delta]
  *   wp      [B][N+1][4] car-frame waypoints, p [B][N+1] speeds, d_hat [B] (OFL) or NULL
  *   lin_x   [B][6][N+1], lin_u [B][N]  LPV prev_x / prev_u, read and updated (NULL otherwise)
- *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B] (0 ok, 2 iteration cap), iters_out [B]
+ *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B], iters_out [B]
+ *   status: 0 ok; 2 interior-point iteration cap; 3 speed differs from the exclusive fixed-model cache; 4 the start
+ *   steering angle lies so far outside its bound that the reference's QP is infeasible (acados raises there): the
+ *   bound was widened along the fastest way back inside and that problem solved instead
  * MPC_KIND_NL (NLMPC.py:214-252): lin_u [B][N] is required and holds the SQP iterate, read as the starting point and
  * updated with the solution, the way the reference's solver object keeps its iterate from call to call (zeros before
  * the first call); lin_x is not used; traj_out rows are the 7 NL states [x, y, cos, sin, vy, r, delta]; status 1 =

@@ -76,7 +76,7 @@ class _CondensedMpc:
     n_outputs = 5
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
-                 batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 60,
+                 batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
                  _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
@@ -232,6 +232,19 @@ class _CondensedMpc:
         elif st != 0:
             raise RuntimeError(f"MPC solve failed with status {st}")
         return 0, traj, U.reshape(self.N, 1)
+
+    def set_model_params(self, mp_per_scenario):
+        """Per-scenario model parameters (batch, 6) = [m, I_z, lf, lr, Cf, Cr] for tyre / mass sweeps; None restores the
+        parameters of the yaml file for every scenario.  The fixed-model cache is bypassed while they are set."""
+        if mp_per_scenario is None:
+            rc = self.solver._lib.mpc_set_model_params(self.solver.h, None)
+        else:
+            mp = _dev.f64(np.ascontiguousarray(mp_per_scenario, dtype=np.float64), self.device)
+            if tuple(mp.shape) != (self.batch, 6):
+                raise ValueError(f"model parameters must be ({self.batch}, 6)")
+            torch.cuda.synchronize(self.device)
+            rc = self.solver._lib.mpc_set_model_params(self.solver.h, _dev.ptr(mp))
+        _lib.check(rc, self.solver.h, "mpc_set_model_params")
 
     def condense_fixed(self, vx, exclusive: bool = False):
         """Cache the condensed problem for a constant speed profile (None switches the cache off).  With

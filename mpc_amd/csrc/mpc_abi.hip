@@ -66,7 +66,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
     h->cfg = *cfg;
     mpc::DevCfg &d = h->dev;
-    d.kind = cfg->kind; d.N = cfg->N; d.lpv_lin_prev = cfg->lpv_lin_prev; d.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 60;
+    d.kind = cfg->kind; d.N = cfg->N; d.lpv_lin_prev = cfg->lpv_lin_prev; d.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 80;
     d.dt = cfg->dt; d.eps = cfg->eps; d.max_steering = cfg->max_steering; d.max_rate = cfg->max_rate;
     d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-15; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
     memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);

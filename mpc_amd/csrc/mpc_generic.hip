@@ -6,7 +6,7 @@
 // (column-major, thread-contiguous, so the factorisation runs without bank conflicts and without unrolled code).
 // It serves horizons that have no register-resident instantiation, e.g. the LPV controller's N = 80
 // (plot_generator.py:604) or the N = 50..90 sweep of plot_generator.py:46-75.
-#include "mpc_wave.hpp"
+#include "mpc_ipm.hpp"
 
 #pragma clang fp contract(fast)
 
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         wave_sync();
 
         // ------------------------------------------------------------ 4. solve
-        const double up_d = dmax - xh5, lo_d = -dmax - xh5;
+        double up_d[R], lo_d[R];
+        bool relaxed = false;
+#pragma unroll
+        for (int q = 0; q < R; q++) steer_bounds(xh5, dmax, umax, dt, lane + WAVE * q, up_d[q], lo_d[q], relaxed);
         double dinv[R];
         lds_factor<R>(M, LD, N, lane, dinv);
         Vec<R> U;
@@ -342,24 +345,26 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 ok = ok && fabs(Uu.v[q]) <= umax;
-                if (validd[q]) ok = ok && (dt * vd.v[q] <= up_d) && (dt * vd.v[q] >= lo_d);
+                if (validd[q]) ok = ok && (dt * vd.v[q] <= up_d[q]) && (dt * vd.v[q] >= lo_d[q]);
             }
             if (__all(ok)) U = Uu;
             else constrained = 1;
         }
         if (constrained) {
             const double gscale = fmax(1.0, vmaxabs<R>(g));
+            const double lam0 = fmax(1.0, 0.01 * gscale);
             Vec<R> tpu, tmu, lpu, lmu, tpd, tmd, lpd, lmd;
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 U.v[q] = 0.0;
                 tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
-                lpu.v[q] = valid[q] ? 1.0 : 0.0; lmu.v[q] = lpu.v[q];
-                tpd.v[q] = validd[q] ? fmax(up_d, 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d, 0.1 * dmax) : 1.0;
-                lpd.v[q] = validd[q] ? 1.0 : 0.0; lmd.v[q] = lpd.v[q];
+                lpu.v[q] = valid[q] ? lam0 : 0.0; lmu.v[q] = lpu.v[q];
+                tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
+                lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
             }
             const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
             double res_prev = 1e300;
+            Vec<R> U_last = U;
 #pragma unroll 1
             for (;;) {
                 Vec<R> hu;
@@ -381,15 +386,18 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 for (int q = 0; q < R; q++) {
                     rd.v[q] = valid[q] ? hu.v[q] + g.v[q] + (lpu.v[q] - lmu.v[q]) + dt * sl.v[q] : 0.0;
                     rppu.v[q] = valid[q] ? U.v[q] + tpu.v[q] - umax : 0.0; rpmu.v[q] = valid[q] ? -U.v[q] + tmu.v[q] - umax : 0.0;
-                    rppd.v[q] = validd[q] ? dt * vd.v[q] + tpd.v[q] - up_d : 0.0;
-                    rpmd.v[q] = validd[q] ? -dt * vd.v[q] + tmd.v[q] + lo_d : 0.0;
+                    rppd.v[q] = validd[q] ? dt * vd.v[q] + tpd.v[q] - up_d[q] : 0.0;
+                    rpmd.v[q] = validd[q] ? -dt * vd.v[q] + tmd.v[q] + lo_d[q] : 0.0;
                     musum += tpu.v[q] * lpu.v[q] + tmu.v[q] * lmu.v[q] + tpd.v[q] * lpd.v[q] + tmd.v[q] * lmd.v[q];
                     rpmax = fmax(rpmax, fmax(fmax(fabs(rppu.v[q]), fabs(rpmu.v[q])), fmax(fabs(rppd.v[q]), fabs(rpmd.v[q]))));
                 }
                 mu = wave_sum(musum) * inv_nc;
                 res = fmax(vmaxabs<R>(rd) / gscale, wave_max(rpmax));
                 if (mu <= cfg.tol_mu && (res <= cfg.tol_res || res >= 0.5 * res_prev)) break;
+                if (mu <= 1e-3 * cfg.tol_mu) { if (res > 1e3 * cfg.tol_res) status = 2; break; }   // see interior_point()
+                if (!(mu == mu)) { U = U_last; status = 2; break; }
                 if (iters >= cfg.max_iter) { status = 2; break; }
+                U_last = U;
                 res_prev = res;
                 Vec<R> Du, Dd;
 #pragma unroll
@@ -413,7 +421,8 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                     dU.v[q] = 0; dtpu.v[q] = 0; dtmu.v[q] = 0; dlpu.v[q] = 0; dlmu.v[q] = 0;
                     dtpd.v[q] = 0; dtmd.v[q] = 0; dlpd.v[q] = 0; dlmd.v[q] = 0;
                 }
-                double sigmu = 0.0, alpha = 1.0;
+                const bool safe = iters >= IPM_SAFE_AFTER;      // long-step path following, see interior_point()
+                double sigmu = safe ? 0.25 * mu : 0.0, alpha = 1.0;
 #pragma unroll 1
                 for (int pass = 0; pass < 2; pass++) {
                     Vec<R> rcpu, rcmu, rcpd, rcmd, wd, rhs;
@@ -421,7 +430,9 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                     for (int q = 0; q < R; q++) {
                         rcpu.v[q] = tpu.v[q] * lpu.v[q]; rcmu.v[q] = tmu.v[q] * lmu.v[q];
                         rcpd.v[q] = tpd.v[q] * lpd.v[q]; rcmd.v[q] = tmd.v[q] * lmd.v[q];
-                        if (pass) {
+                        if (safe) {
+                            rcpu.v[q] -= sigmu; rcmu.v[q] -= sigmu; rcpd.v[q] -= sigmu; rcmd.v[q] -= sigmu;
+                        } else if (pass) {
                             rcpu.v[q] += dtpu.v[q] * dlpu.v[q] - sigmu; rcmu.v[q] += dtmu.v[q] * dlmu.v[q] - sigmu;
                             rcpd.v[q] += dtpd.v[q] * dlpd.v[q] - sigmu; rcmd.v[q] += dtmd.v[q] * dlmd.v[q] - sigmu;
                         }
@@ -456,6 +467,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                         if (dlmd.v[q] < 0) al = fmin(al, -lmd.v[q] / dlmd.v[q]);
                     }
                     alpha = wave_min(al);
+                    if (safe) break;
                     if (pass == 0) {
                         double ms = 0.0;
 #pragma unroll
@@ -466,7 +478,33 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                         sigmu = sg * sg * sg * mu;
                     }
                 }
-                alpha *= 0.995;
+                if (!safe) {
+                    alpha *= fmin(fmax(0.995, 1.0 - mu), 0.999999);   // never onto the boundary itself
+                } else {
+                    const double big = 1e300;
+                    double mp = big;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        if (valid[q]) mp = fmin(mp, fmin(tpu.v[q] * lpu.v[q], tmu.v[q] * lmu.v[q]));
+                        if (validd[q]) mp = fmin(mp, fmin(tpd.v[q] * lpd.v[q], tmd.v[q] * lmd.v[q]));
+                    }
+                    const double gam = fmin(0.01, 0.5 * wave_min(mp) / mu);
+                    alpha *= 0.99;
+#pragma unroll 1
+                    for (int bt = 0; bt < 20; bt++) {
+                        double sum = 0.0, mn = big;
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            const double p1 = (tpu.v[q] + alpha * dtpu.v[q]) * (lpu.v[q] + alpha * dlpu.v[q]), p2 = (tmu.v[q] + alpha * dtmu.v[q]) * (lmu.v[q] + alpha * dlmu.v[q]);
+                            const double p3 = (tpd.v[q] + alpha * dtpd.v[q]) * (lpd.v[q] + alpha * dlpd.v[q]), p4 = (tmd.v[q] + alpha * dtmd.v[q]) * (lmd.v[q] + alpha * dlmd.v[q]);
+                            sum += p1 + p2 + p3 + p4;
+                            if (valid[q]) mn = fmin(mn, fmin(p1, p2));
+                            if (validd[q]) mn = fmin(mn, fmin(p3, p4));
+                        }
+                        if (wave_min(mn) >= gam * wave_sum(sum) * inv_nc) break;
+                        alpha *= 0.6;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     U.v[q] = fma(alpha, dU.v[q], U.v[q]);
@@ -479,6 +517,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             }
         }
 
+        if (relaxed) status = max(status, 4);
         // ------------------------------------------------------------ 5. outputs, prediction, plant, estimator
 #pragma unroll
         for (int q = 0; q < R; q++)

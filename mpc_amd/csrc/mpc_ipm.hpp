@@ -58,14 +58,37 @@ struct Newton {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Mehrotra predictor-corrector on  G U + t = h,  G = [A; -A],  A = [I; dt * prefix-sum].
-// H is read from memory (Hm[j*N + lane], symmetric); returns the solver status (0 converged, 2 iteration cap).
+// Bounds on delta_{lane+1} - delta_0 = dt * (prefix sum of U)[lane].  |delta_k| <= dmax holds for stages 1..N-1
+// (LMPC2.py:196-210).  When the start value delta_0 lies so far outside that even the full steering rate cannot bring
+// stage 1 back inside, the reference's QP has no feasible point (acados raises); here the bound is then widened along
+// the way back in at 98% of the full rate, so that a solution exists, and `relaxed` tells the caller to flag it.
+__device__ __forceinline__ void steer_bounds(double d0, double dmax, double umax, double dt, int lane, double &up,
+                                             double &lo, bool &relaxed)
+{
+    const double reach = 0.98 * umax * dt * (double)(lane + 1);
+    up = fmax(dmax, d0 - reach) - d0;
+    lo = fmin(-dmax, d0 + reach) - d0;
+    relaxed = fabs(d0) - 0.98 * umax * dt > dmax;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mehrotra predictor-corrector on  G U + t = h,  G = [A; -A],  A = [I; dt * prefix-sum], with the multipliers started
+// at 1% of the gradient's size and a fraction-to-the-boundary of min(max(0.995, 1 - mu), 0.999999).  The predictor-
+// corrector has no centrality control and, rarely (order 1e-5 of the problems met in closed loop), settles into a cycle
+// of short steps; after IPM_SAFE_AFTER iterations the loop therefore continues as a long-step path-following method
+// (fixed centering 0.25, no second-order term, step cut back until every slack-multiplier product stays above a fixed
+// fraction of their mean), which converges from any interior point.
+// H is read from memory (Hm[j*N + lane], symmetric); up_d / lo_d are this lane's steer_bounds().
+// Returns the solver status (0 converged, 2 iteration cap).
 //
 // Deliberately NOT inlined: it runs on the minority of steps whose unconstrained minimiser violates a bound, and
 // as a real call its ~250 registers (the Newton-matrix row alone is 2N) stay out of the register allocation of
 // the per-step hot path; the caller's live state is saved around the call only when the call happens.
+constexpr int IPM_SAFE_AFTER = 25;
+
 template <int N>
-__device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double xh5)
+__device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double up_d,
+                                                 double lo_d)
 {
     Newton<N> nt;
     double U, mu, res;
@@ -73,16 +96,16 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
     const bool valid = lane < N, validd = lane < N - 1;
     const double dt = prm.dt, dt2 = dt * dt;
     const double umax = prm.umax, dmax = prm.dmax;
-    const double up_d = dmax - xh5, lo_d = -dmax - xh5;
     const double gscale = fmax(1.0, wave_max(fabs(g)));
-    double tpu, tmu, lpu = 1.0, lmu = 1.0, tpd, tmd, lpd = 1.0, lmd = 1.0;
+    const double lam0 = fmax(1.0, 0.01 * gscale);
+    double tpu, tmu, lpu = lam0, lmu = lam0, tpd, tmd, lpd = lam0, lmd = lam0;
     U = 0.0;
     tpu = umax; tmu = umax;
     tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax);
     if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
     if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
     const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
-    double res_prev = 1e300;
+    double res_prev = 1e300, U_last = 0.0;
     int status = 0;
     iters = 0;
 #pragma unroll 1
@@ -105,7 +128,12 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
         res = fmax(resd / gscale, resp);
         // stop at the tolerances, or once the residual has reached the arithmetic's floor and stopped improving
         if (mu <= prm.tol_mu && (res <= prm.tol_res || res >= 0.5 * res_prev)) break;
+        // complementarity far below its target: the Newton matrix is about to lose its small eigenvalues to rounding
+        // (the steering rows add dt^2 * sum(lambda/t) to every entry); accept a residual within 1000x of its tolerance
+        if (mu <= 1e-3 * prm.tol_mu) { status = res <= 1e3 * prm.tol_res ? 0 : 2; break; }
+        if (!(mu == mu)) { U = U_last; status = 2; break; }          // arithmetic broke down: keep the last finite iterate
         if (iters >= prm.max_iter) { status = 2; break; }
+        U_last = U;
         res_prev = res;
         // Newton matrix  K = H + diag(Du) + dt^2 * Sfx[max(i,j)],  Sfx = suffix sums of Dd
         const double Du = lpu / tpu + lmu / tmu;
@@ -123,11 +151,14 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
         }
         nt.factor(lane);
         double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
-        double sigmu = 0.0, alpha = 1.0;
+        const bool safe = iters >= IPM_SAFE_AFTER;
+        double sigmu = safe ? 0.25 * mu : 0.0, alpha = 1.0;
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
             double rcpu = tpu * lpu, rcmu = tmu * lmu, rcpd = tpd * lpd, rcmd = tmd * lmd;
-            if (pass) {
+            if (safe) {
+                rcpu -= sigmu; rcmu -= sigmu; rcpd -= sigmu; rcmd -= sigmu;
+            } else if (pass) {
                 rcpu += dtpu * dlpu - sigmu; rcmu += dtmu * dlmu - sigmu;
                 rcpd += dtpd * dlpd - sigmu; rcmd += dtmd * dlmd - sigmu;
             }
@@ -154,6 +185,7 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
             if (dlpd < 0) al = fmin(al, -lpd / dlpd);
             if (dlmd < 0) al = fmin(al, -lmd / dlmd);
             alpha = wave_min(al);
+            if (safe) break;
             if (pass == 0) {
                 const double mua = wave_sum((tpu + alpha * dtpu) * (lpu + alpha * dlpu) +
                                             (tmu + alpha * dtmu) * (lmu + alpha * dlmu) +
@@ -163,7 +195,26 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
                 sigmu = sg * sg * sg * mu;
             }
         }
-        alpha *= 0.995;
+        if (!safe) {
+            alpha *= fmin(fmax(0.995, 1.0 - mu), 0.999999);   // never onto the boundary itself
+        } else {
+            // neighbourhood of the central path: no product may fall below gam times the mean (gam from the current
+            // point if that is already worse than 0.01)
+            const double big = 1e300;
+            const double minp0 = wave_min(fmin(fmin(valid ? tpu * lpu : big, valid ? tmu * lmu : big),
+                                               fmin(validd ? tpd * lpd : big, validd ? tmd * lmd : big)));
+            const double gam = fmin(0.01, 0.5 * minp0 / mu);
+            alpha *= 0.99;
+#pragma unroll 1
+            for (int bt = 0; bt < 20; bt++) {
+                const double p1 = (tpu + alpha * dtpu) * (lpu + alpha * dlpu), p2 = (tmu + alpha * dtmu) * (lmu + alpha * dlmu);
+                const double p3 = (tpd + alpha * dtpd) * (lpd + alpha * dlpd), p4 = (tmd + alpha * dtmd) * (lmd + alpha * dlmd);
+                const double mun = wave_sum(p1 + p2 + p3 + p4) * inv_nc;
+                const double minp = wave_min(fmin(fmin(valid ? p1 : big, valid ? p2 : big), fmin(validd ? p3 : big, validd ? p4 : big)));
+                if (minp >= gam * mun) break;
+                alpha *= 0.6;
+            }
+        }
         U = fma(alpha, dU, U);
         tpu = fma(alpha, dtpu, tpu); tmu = fma(alpha, dtmu, tmu);
         lpu = fma(alpha, dlpu, lpu); lmu = fma(alpha, dlmu, lmu);

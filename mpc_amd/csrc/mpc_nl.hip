@@ -207,7 +207,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
             if (valid) { s_coef[lane * 4] = a11; s_coef[lane * 4 + 1] = a12; s_coef[lane * 4 + 2] = a21; s_coef[lane * 4 + 3] = a22; }
         }
         wave_sync();
-        const double up_d = dmax - xh[6], lo_d = -dmax - xh[6];
+        double up_d, lo_d;
+        bool relaxed;
+        steer_bounds(xh[6], dmax, umax, dt, lane, up_d, lo_d, relaxed);
 
         // ------------------------------------------------------------ 2. SQP iterations
         int iters = 0, status = 1, sqp = 0;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
             if (!__all(ok)) {
                 nconstr++;
                 const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
-                const IpmResult r = interior_point<N>(prm, lane, Hw, gq, xh[6]);
+                const IpmResult r = interior_point<N>(prm, lane, Hw, gq, up_d, lo_d);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
             }
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
             if (step <= cfg.sqp_tol || (step <= 1e3 * cfg.sqp_tol && step >= 0.5 * step_prev)) status = 0;
             step_prev = step;
         }
+        if (relaxed) status_max = max(status_max, 4);
         sqp_tot += sqp;
         iters_tot += iters;
         status_max = max(status_max, status);

@@ -250,7 +250,9 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
                         &s_stage[lane * STAGE_W]);
 
         // ------------------------------------------------------------ 3. condense, 4. solve
-        const double up_d = dmax - xh5, lo_d = -dmax - xh5;     // bounds on dt * prefix sum
+        double up_d, lo_d;                                       // bounds on dt * prefix sum, per lane
+        bool relaxed;
+        steer_bounds(xh5, dmax, umax, dt, lane, up_d, lo_d, relaxed);
         double g = 0.0, U = 0.0;
         int iters = 0, status = 0, constrained = 0;
         const double *Hm;
@@ -330,9 +332,10 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
         }
         if (constrained) {
             const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
-            const IpmResult r = interior_point<N>(prm, lane, Hm, g, xh5);
+            const IpmResult r = interior_point<N>(prm, lane, Hm, g, up_d, lo_d);
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
         }
+        if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible
 
         // ------------------------------------------------------------ 5. outputs, prediction, plant
         if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;

@@ -106,3 +106,33 @@ def test_fused_run_equals_step_by_step(N, Tf):
     assert torch.equal(us_a, us_b)
     assert torch.equal(a.state, b.state) and torch.equal(a.state, xs_b[-1])
     assert torch.equal(a.lap, b.lap) and torch.equal(a.prev_progress, b.prev_progress)
+
+
+def test_out_of_reach_steering_start_is_relaxed_and_flagged(orc80):
+    """A start steering angle beyond the bound by more than one step of full rate makes the reference's QP infeasible
+    (acados raises there).  Library and checker both solve the problem with the bound widened along the way back inside
+    and flag it with status 4; angles that one step can still bring back are solved as posed (status 0)."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.controllers import LOcp, OFLOcp
+    N, Tf = 50, 0.5
+    deltas = [0.33, -0.36, 0.305, 0.3, -0.3087]
+    for kind, cls in (("L", LOcp), ("OFL", OFLOcp)):
+        cfg = O.make_cfg(kind, N, Tf)
+        ctl = cls(N, Tf, batch=len(deltas))
+        st = np.array([[15.0, 0.1 * (-1) ** i, 1, 0, 8.0, 0.05, -0.05, d] for i, d in enumerate(deltas)])
+        x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]
+        wps, ps = [], []
+        for s in st:
+            wp, sp, _, _ = orc80.skidpad_waypoints(s[0], s[1], 0.0, 0, 0.0, s[4], N, Tf / N)
+            wps.append(wp); ps.append(sp)
+        dh = np.full(len(deltas), -9.0) if kind == "OFL" else None
+        U, traj, status, iters = ctl.solve_batched(x0, np.array(wps), np.array(ps), dh)
+        torch.cuda.synchronize()
+        U = U.cpu().numpy(); status = status.cpu().numpy()
+        assert status.tolist() == [4, 4, 0, 0, 0]
+        for b in range(len(deltas)):
+            stt, traj_ref, U_ref, lam, info = orc80.optimize(cfg, x0[b], wps[b], ps[b], 0.0 if dh is None else dh[b])
+            assert stt == status[b]
+            assert (np.abs(U[b] - U_ref) <= _tol(U_ref)).all(), (kind, b, np.abs(U[b] - U_ref).max())
+        assert np.isfinite(U).all()
