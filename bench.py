@@ -89,6 +89,16 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
                       f"included), oracle/mpc_oracle.c double build, OpenMP over scenarios, {dtm:.1f} s"}
 
 
+def measured_traffic(args):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this process); only
+    for the configuration those passes were taken on, else None."""
+    path = os.path.join(ROOT, "profiles", "r01b_c2_fused_hbm_traffic.json")
+    if args.workload != "c2" or args.per_step_launch or args.steps != 1000 or args.batch not in (None, 4096) or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["hbm_bytes_per_launch"]
+
+
 WORKLOADS = {
     "c2": {"kind": "L", "N": 50, "Tf": 0.5, "B": 4096, "kernel": "k_mpc<50, fixed-model>",
            "text": "LMPC2 batched: 4096 perturbed skidpad initial states per GPU, fixed A,B (vx=8), N=50, dt=0.01, closed loop"},
@@ -253,7 +263,7 @@ def main() -> None:
                        "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(torch.bincount(sim.status.long()).tolist()) if v},
                        "transient_scenario_steps_per_s": (B * world * args.warmup / t_warm) if args.warmup else None},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": measured_traffic(args),
                          "kernel": wl["kernel"], "avg_launch_ms": launch_s * 1e3,
                          "scenario_steps_per_launch": B * steps_per_launch,
                          "algorithmic_flops_per_scenario_step": flops,

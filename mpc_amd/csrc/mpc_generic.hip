@@ -475,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                             ms += (tpu.v[q] + alpha * dtpu.v[q]) * (lpu.v[q] + alpha * dlpu.v[q]) + (tmu.v[q] + alpha * dtmu.v[q]) * (lmu.v[q] + alpha * dlmu.v[q]) +
                                   (tpd.v[q] + alpha * dtpd.v[q]) * (lpd.v[q] + alpha * dlpd.v[q]) + (tmd.v[q] + alpha * dtmd.v[q]) * (lmd.v[q] + alpha * dlmd.v[q]);
                         const double sg = wave_sum(ms) * inv_nc / mu;
-                        sigmu = sg * sg * sg * mu;
+                        sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));   // the gap must not outrun the residuals
                     }
                 }
                 if (!safe) {

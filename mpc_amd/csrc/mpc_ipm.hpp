@@ -192,7 +192,7 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
                                             (tpd + alpha * dtpd) * (lpd + alpha * dlpd) +
                                             (tmd + alpha * dtmd) * (lmd + alpha * dlmd)) * inv_nc;
                 const double sg = mua / mu;
-                sigmu = sg * sg * sg * mu;
+                sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));   // the gap must not outrun the residuals
             }
         }
         if (!safe) {

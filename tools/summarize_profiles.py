@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 databases of tools/profile_round.sh (gpurun_out/prof/*) into the small per-kernel summaries
+kept under profiles/: calls, total, average, min, max duration and register/LDS/scratch figures per kernel, plus the
+HBM counter totals per dispatch of the two --pmc passes."""
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r01b"
+os.makedirs(dst, exist_ok=True)
+for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
+    name = os.path.basename(os.path.dirname(db))
+    con = sqlite3.connect(db)
+    rows = con.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
+        "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
+        "from kernels group by name order by sum(duration) desc").fetchall()
+    with open(os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "vgpr", "agpr", "sgpr", "lds_bytes",
+                    "scratch_bytes", "grid_x", "workgroup_x"])
+        for r in rows[:12]:
+            w.writerow([r[0][:120]] + [int(v) if v is not None else "" for v in r[1:]])
+    pmc = con.execute("select count(*) from pmc_events").fetchone()[0]
+    if pmc:
+        cols = [r[1] for r in con.execute("pragma table_info('counters_collection')")]
+        q = con.execute("select kernel_name, counter_name, count(*), sum(value), avg(value) from counters_collection "
+                        "group by kernel_name, counter_name order by sum(value) desc").fetchall() if "kernel_name" in cols else []
+        with open(os.path.join(dst, f"{tag}_{name}_counters.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "counter", "dispatches", "sum", "avg_per_dispatch"])
+            for r in q[:12]:
+                w.writerow([r[0][:120], r[1], int(r[2]), r[3], r[4]])
+    print(name, "kernels:", [(r[0][:40], r[1], round(r[3])) for r in rows[:3]], "pmc rows", pmc)
