@@ -66,9 +66,27 @@ __device__ __forceinline__ void lat_coeffs(const ModelParams &mp, double vx, dou
     a22 = -(mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr) / (mp.Iz * vx + eps);
 }
 
-// Plant right-hand side (continuous_dynamics.py:90-124); x has NX = 8 or 10 entries.
+// Speed-dependent coefficients of the plant's lateral rows.  The longitudinal speed x[4] has zero derivative, so every
+// stage of an RK4 step (and every step of a run) divides by the same values: computing the quotients once gives the
+// same bits as evaluating continuous_dynamics.py:104-118 term by term.
+struct PlantCoef { double vx, c11, c12a, b1, c21, c22, b2; };
+
+__device__ __forceinline__ PlantCoef plant_coef(const ModelParams &mp, double vx)
+{
+    PlantCoef c;
+    c.vx = vx;
+    c.c11 = -(mp.Cf + mp.Cr) / (mp.m * vx);
+    c.c12a = (mp.Cr * mp.lr - mp.Cf * mp.lf) / (mp.m * vx);
+    c.b1 = mp.Cf / mp.m;
+    c.c21 = (mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * vx);
+    c.c22 = (mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr) / (mp.Iz * vx);
+    c.b2 = (mp.Cf * mp.lf) / mp.Iz;
+    return c;
+}
+
+// Plant right-hand side (continuous_dynamics.py:90-124); x has NX = 8 or 10 entries; c = plant_coef(mp, x[4]).
 template <int NX>
-__device__ __forceinline__ void plant_f(const double *x, double u, const ModelParams &mp, double *xd)
+__device__ __forceinline__ void plant_f_c(const double *x, double u, const PlantCoef &c, double *xd)
 {
     double sd = 0.0, fd = 0.0;
     if (NX == 10) { sd = x[8]; fd = x[9]; }
@@ -77,33 +95,41 @@ __device__ __forceinline__ void plant_f(const double *x, double u, const ModelPa
     xd[2] = -x[6] * x[3];
     xd[3] = x[6] * x[2];
     xd[4] = 0.0;
-    xd[5] = ((-(mp.Cf + mp.Cr) / (mp.m * x[4]) * x[5] +
-              (-x[4] + (mp.Cr * mp.lr - mp.Cf * mp.lf) / (mp.m * x[4])) * x[6]) -
-             mp.Cf / mp.m * (x[7] + sd) + fd);
-    xd[6] = ((mp.lr * mp.Cr - mp.lf * mp.Cf) / (mp.Iz * x[4]) * x[5] -
-             (mp.lf * mp.lf * mp.Cf + mp.lr * mp.lr * mp.Cr) / (mp.Iz * x[4]) * x[6] -
-             (mp.Cf * mp.lf) / mp.Iz * (x[7] + sd));
+    xd[5] = ((c.c11 * x[5] + (-x[4] + c.c12a) * x[6]) - c.b1 * (x[7] + sd) + fd);
+    xd[6] = (c.c21 * x[5] - c.c22 * x[6] - c.b2 * (x[7] + sd));
     xd[7] = u;
     if (NX == 10) { xd[8] = 0.0; xd[9] = 0.0; }
 }
 
-// Classic RK4 with the input held (continuous_dynamics.py:126-133).
+template <int NX>
+__device__ __forceinline__ void plant_f(const double *x, double u, const ModelParams &mp, double *xd)
+{
+    plant_f_c<NX>(x, u, plant_coef(mp, x[4]), xd);
+}
+
+// Classic RK4 with the input held (continuous_dynamics.py:126-133); c = plant_coef(mp, x[4]).
+template <int NX>
+__device__ __forceinline__ void plant_rk4_c(double *x, double u, double dt, const PlantCoef &c)
+{
+    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
+    plant_f_c<NX>(x, u, c, k1);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k1[i];
+    plant_f_c<NX>(t, u, c, k2);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k2[i];
+    plant_f_c<NX>(t, u, c, k3);
+#pragma unroll
+    for (int i = 0; i < NX; i++) t[i] = x[i] + dt * k3[i];
+    plant_f_c<NX>(t, u, c, k4);
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+}
+
 template <int NX>
 __device__ __forceinline__ void plant_rk4(double *x, double u, double dt, const ModelParams &mp)
 {
-    double k1[NX], k2[NX], k3[NX], k4[NX], t[NX];
-    plant_f<NX>(x, u, mp, k1);
-#pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k1[i];
-    plant_f<NX>(t, u, mp, k2);
-#pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + dt / 2 * k2[i];
-    plant_f<NX>(t, u, mp, k3);
-#pragma unroll
-    for (int i = 0; i < NX; i++) t[i] = x[i] + dt * k3[i];
-    plant_f<NX>(t, u, mp, k4);
-#pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+    plant_rk4_c<NX>(x, u, dt, plant_coef(mp, x[4]));
 }
 
 // ---------------------------------------------------------------- EKF linearisation
@@ -150,17 +176,30 @@ __device__ __forceinline__ double sk_pos2progress(double x, double y, int lap)
     return x + 4 * SK_LAP;
 }
 
-// utils/path_planning.py:131-167; "a // b > 0" with b > 0 is "a >= b".
+// utils/path_planning.py:131-167; "a // b > 0" with b > 0 is "a >= b".  One sincos per pose: the second circle's
+// position angle a = b - 4 pi has the sine and cosine of b (the reference evaluates both angles; the two agree to the
+// rounding of b, a few 1e-15).
 __device__ __forceinline__ void sk_pose(double q, double *o)
 {
+    const double b = (q - SK_CENTER) / SK_R;
     if (q - SK_CENTER >= 4 * SK_LAP) { o[0] = q - 4 * SK_LAP; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
-    else if (q - SK_CENTER >= 2 * SK_LAP) {
-        double a = (q - SK_CENTER - 2 * SK_LAP) / SK_R, b = (q - SK_CENTER) / SK_R;
-        o[0] = SK_CENTER + sin(a) * SK_R; o[1] = SK_R - cos(a) * SK_R; o[2] = cos(b); o[3] = sin(b);
-    } else if (q - SK_CENTER > 0) {
-        double b = (q - SK_CENTER) / SK_R;
-        o[0] = SK_CENTER + sin(b) * SK_R; o[1] = -SK_R + cos(b) * SK_R; o[2] = cos(b); o[3] = -sin(b);
+    else if (q - SK_CENTER > 0) {
+        double sb, cb;
+        sincos(b, &sb, &cb);
+        if (q - SK_CENTER >= 2 * SK_LAP) { o[0] = SK_CENTER + sb * SK_R; o[1] = SK_R - cb * SK_R; o[2] = cb; o[3] = sb; }
+        else { o[0] = SK_CENTER + sb * SK_R; o[1] = -SK_R + cb * SK_R; o[2] = cb; o[3] = -sb; }
     } else { o[0] = q; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+}
+
+// cos and sin of atan2(hs, hc) without the angle: the heading vector normalised (skidpad_simulator.py:104 takes the
+// angle and path_planning.py:253-260 its cosine and sine again)
+__device__ __forceinline__ void unit_heading(double hc, double hs, double &ch, double &sh)
+{
+    const double n2 = hc * hc + hs * hs;
+    if (n2 > 0.0) {
+        const double rn = 1.0 / sqrt(n2);
+        ch = hc * rn; sh = hs * rn;
+    } else { ch = 1.0; sh = 0.0; }
 }
 
 // translate by the car position and right-multiply by [[c,-s],[s,c]] (path_planning.py:253-260)
@@ -173,13 +212,20 @@ __device__ __forceinline__ void to_car_frame(double *o, double x, double y, doub
     o[3] = -hx * sh + hy * ch;
 }
 
-// progress of waypoint k: p0 + cumsum(speeds[:-1])[k-1] * dt with np.cumsum's sequential accumulation
+// cumsum(speeds[:-1])[k-1] for a constant speed v with np.cumsum's sequential accumulation (0 for k = 0)
+__device__ __forceinline__ double speed_cumsum(double v, int k)
+{
+    if (k == 0) return 0.0;
+    double cs = v;
+    for (int i = 1; i < k; i++) cs += v;
+    return cs;
+}
+
+// progress of waypoint k: p0 + cumsum(speeds[:-1])[k-1] * dt
 __device__ __forceinline__ double waypoint_progress(double p0, double v, double dt, int k)
 {
     if (k == 0) return p0;
-    double cs = v;
-    for (int i = 1; i < k; i++) cs += v;
-    return p0 + cs * dt;
+    return p0 + speed_cumsum(v, k) * dt;
 }
 
 }  // namespace mpc

@@ -170,6 +170,10 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         }
     }
     wave_sync();
+    const PlantCoef pc = plant_coef(mp, plant[4]);             // constant over the launch: x[4] has zero derivative
+    double cs[3];                                              // progress increments of waypoints lane, lane+64, lane+128
+#pragma unroll
+    for (int q = 0; q < 3; q++) cs[q] = (lane + WAVE * q <= N) ? speed_cumsum(tvel, lane + WAVE * q) : 0.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
@@ -195,7 +199,6 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 px = s_xe[0]; py = s_xe[1]; hc = s_xe[2]; hs = s_xe[3];
                 xh3 = s_xe[5]; xh4 = s_xe[6]; xh5 = s_xe[7]; dhat = s_xe[9];
             }
-            const double heading = atan2(hs, hc);
             double p0;
             if (a.mode == MODE_SKIDPAD) {
                 int lp = lapv;
@@ -204,10 +207,14 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 prevp = p0;
             } else
                 p0 = px;
-            const double ch = cos(heading), sh = sin(heading);
-            for (int k = lane; k <= N; k += WAVE) {
+            double ch, sh;
+            unit_heading(hc, hs, ch, sh);
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+                const int k = lane + WAVE * qi;
+                if (k > N) continue;
                 double o[4];
-                const double q = waypoint_progress(p0, tvel, dt, k);
+                const double q = (k == 0) ? p0 : p0 + cs[qi] * dt;
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
                 else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
                 to_car_frame(o, px, py, ch, sh);
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         }
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
-            plant_rk4<10>(plant, u0, dt, mp);
+            plant_rk4_c<10>(plant, u0, dt, pc);
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
         tvel = a.target_vel[s];
         if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
     }
+    const PlantCoef pc = plant_coef(mp, plant[4]);             // constant over the launch: x[4] has zero derivative
+    const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     double U = valid ? a.lin_u[(size_t)s * N + lane] : 0.0;    // SQP iterate, carried from call to call
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0;
@@ -172,7 +174,6 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
         } else {
             const double px = plant[0], py = plant[1];
             xh[4] = plant[5]; xh[5] = plant[6]; xh[6] = plant[7];
-            const double heading = atan2(plant[3], plant[2]);
             double p0;
             if (a.mode == MODE_SKIDPAD) {
                 int lp = lapv;
@@ -181,10 +182,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
                 prevp = p0;
             } else
                 p0 = px;
-            const double ch = cos(heading), sh = sin(heading);
+            double ch, sh;
+            unit_heading(plant[2], plant[3], ch, sh);
             for (int k = lane; k <= N; k += WAVE) {
                 double o[4];
-                const double q = waypoint_progress(p0, tvel, dt, k);
+                const double q = (k == 0) ? p0 : p0 + (k < WAVE ? cs0 : cs1) * dt;
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
                 else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
                 to_car_frame(o, px, py, ch, sh);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
         u0 = bcast(U, 0);
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
-            plant_rk4<10>(plant, u0, dt, mp);
+            plant_rk4_c<10>(plant, u0, dt, pc);
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < 8) {

@@ -189,6 +189,10 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
             wave_sync();
         }
     }
+    // constant over the launch: the plant's speed-dependent coefficients (x[4] has zero derivative) and the progress
+    // increments of the waypoints (sequentially accumulated like np.cumsum)
+    const PlantCoef pc = plant_coef(mp, plant[4]);
+    const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
@@ -216,7 +220,6 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
                 px = s_xe[0]; py = s_xe[1]; hc = s_xe[2]; hs = s_xe[3];
                 xh3 = s_xe[5]; xh4 = s_xe[6]; xh5 = s_xe[7]; dhat = s_xe[9];
             }
-            const double heading = atan2(hs, hc);                          // skidpad_simulator.py:104
             double p0;
             if (a.mode == MODE_SKIDPAD) {
                 int lp = lapv;
@@ -225,10 +228,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
                 prevp = p0;                                                // path_planning.py:251
             } else
                 p0 = px;                                                   // step_planning.py:83-86
-            const double ch = cos(heading), sh = sin(heading);
+            double ch, sh;                                                 // skidpad_simulator.py:104, path_planning.py:253
+            unit_heading(hc, hs, ch, sh);
             for (int k = lane; k <= N; k += WAVE) {
                 double o[4];
-                const double q = waypoint_progress(p0, tvel, dt, k);
+                const double q = (k == 0) ? p0 : p0 + (k < WAVE ? cs0 : cs1) * dt;    // path_planning.py:236-240
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
                 else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }   // step_planning.py:63-80
                 to_car_frame(o, px, py, ch, sh);
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
         }
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
-            plant_rk4<10>(plant, u0, dt, mp);                               // skidpad_simulator.py:128
+            plant_rk4_c<10>(plant, u0, dt, pc);                             // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {
