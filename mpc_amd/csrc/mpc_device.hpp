@@ -14,6 +14,17 @@ __device__ __forceinline__ double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// The same broadcast with the two v_readlane pinned in program order (volatile asm; `src` must fold to a constant).
+// Issued in groups ahead of the arithmetic that consumes them, the reads overlap instead of forming
+// readlane-readlane-wait-fma chains on one SGPR pair.
+__device__ __forceinline__ double bcast_pinned(double v, int src)
+{
+    int lo, hi;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(lo) : "v"(__double2loint(v)), "n"(src));
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(hi) : "v"(__double2hiint(v)), "n"(src));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll

@@ -7,6 +7,8 @@
 
 namespace mpc {
 
+typedef __attribute__((address_space(1))) double gdouble;   // a double in global memory
+
 // ------------------------------------------------------------------------------------------------
 template <int N>
 struct Newton {
@@ -26,10 +28,17 @@ struct Newton {
             const bool below = lane > k;
             const double l = below ? c * inv : 0.0;
             if (lane == k) dinv = inv;
+            // groups of 4: broadcast four pivot-column entries, then the four updates that use them
 #pragma unroll
-            for (int j = k + 1; j < N; j++) {
-                row[j] = fma(-l, bcast(c, j), row[j]);
-                if (((j - k) & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // keep readlane results (SGPRs) short-lived
+            for (int j0 = k + 1; j0 < N; j0 += 4) {
+                double cj[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (j0 + g < N) cj[g] = bcast_pinned(c, j0 + g);
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (j0 + g < N) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
+                __builtin_amdgcn_sched_barrier(0);                           // keep readlane results (SGPRs) short-lived
             }
             if (below) row[k] = l;
             __builtin_amdgcn_sched_barrier(0);
@@ -94,6 +103,7 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
     double U, mu, res;
     int iters;
     const bool valid = lane < N, validd = lane < N - 1;
+    const int lc = valid ? lane : 0;
     const double dt = prm.dt, dt2 = dt * dt;
     const double umax = prm.umax, dmax = prm.dmax;
     const double gscale = fmax(1.0, wave_max(fabs(g)));
@@ -112,10 +122,13 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
     for (;;) {
         // H is re-read from memory (L2-resident) wherever it is needed: laundering the pointer keeps the compiler
         // from hoisting the N loads out of the iteration loop into 2N registers per lane.
-        const double *Hr = opaque_uniform(Hm);
+        // (loads are unconditional from a clamped row index and global-addressed: a predicated generic load costs a
+        // branch and a flat instruction per entry)
+        const gdouble *Hr = (const gdouble *)opaque_uniform(Hm);
         double hu = 0.0;
 #pragma unroll 10
-        for (int j = 0; j < N; j++) hu = fma(valid ? Hr[j * N + lane] : 0.0, bcast(U, j), hu);
+        for (int j = 0; j < N; j++) hu = fma(Hr[j * N + lc], bcast(U, j), hu);
+        if (!valid) hu = 0.0;
         const double vd = dt * incl_prefix(U, lane);
         const double lamd = validd ? (lpd - lmd) : 0.0;
         double rd = hu + g + (lpu - lmu) + dt * incl_suffix(lamd, lane);
@@ -135,15 +148,20 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
         if (iters >= prm.max_iter) { status = 2; break; }
         U_last = U;
         res_prev = res;
+        // reciprocals of the slacks and multipliers, shared by everything below (a quotient costs ~3x a reciprocal)
+        const double itpu = fast_rcp(tpu), itmu = fast_rcp(tmu), itpd = fast_rcp(tpd), itmd = fast_rcp(tmd);
+        const double ilpu = valid ? fast_rcp(lpu) : 0.0, ilmu = valid ? fast_rcp(lmu) : 0.0;
+        const double ilpd = validd ? fast_rcp(lpd) : 0.0, ilmd = validd ? fast_rcp(lmd) : 0.0;
         // Newton matrix  K = H + diag(Du) + dt^2 * Sfx[max(i,j)],  Sfx = suffix sums of Dd
-        const double Du = lpu / tpu + lmu / tmu;
-        const double Dd = validd ? lpd / tpd + lmd / tmd : 0.0;
+        const double Du = lpu * itpu + lmu * itmu;
+        const double Dd = validd ? lpd * itpd + lmd * itmd : 0.0;
         const double sfx = incl_suffix(Dd, lane);
-        const double *Hk = opaque_uniform(Hm);
+        const gdouble *Hk = (const gdouble *)opaque_uniform(Hm);
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const double sj = bcast(sfx, j);
-            double kij = valid ? Hk[j * N + lane] : 0.0;
+            double kij = Hk[j * N + lc];
+            if (!valid) kij = 0.0;
             kij = fma(dt2, (j > lane) ? sj : sfx, kij);
             if (j == lane) kij += Du;
             nt.row[j] = kij;
@@ -162,29 +180,24 @@ __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const 
                 rcpu += dtpu * dlpu - sigmu; rcmu += dtmu * dlmu - sigmu;
                 rcpd += dtpd * dlpd - sigmu; rcmd += dtmd * dlmd - sigmu;
             }
-            const double wu = (lpu * rppu - rcpu) / tpu - (lmu * rpmu - rcmu) / tmu;
-            const double wd = validd ? (lpd * rppd - rcpd) / tpd - (lmd * rpmd - rcmd) / tmd : 0.0;
+            const double wu = (lpu * rppu - rcpu) * itpu - (lmu * rpmu - rcmu) * itmu;
+            const double wd = validd ? (lpd * rppd - rcpd) * itpd - (lmd * rpmd - rcmd) * itmd : 0.0;
             double rhs = -rd - wu - dt * incl_suffix(wd, lane);
             if (!valid) rhs = 0.0;
             dU = nt.solve(rhs, lane);
             if (!valid) dU = 0.0;
             const double dvd = dt * incl_prefix(dU, lane);
             dtpu = -rppu - dU; dtmu = -rpmu + dU;
-            dlpu = -(rcpu + lpu * dtpu) / tpu; dlmu = -(rcmu + lmu * dtmu) / tmu;
+            dlpu = -(rcpu + lpu * dtpu) * itpu; dlmu = -(rcmu + lmu * dtmu) * itmu;
             dtpd = -rppd - dvd; dtmd = -rpmd + dvd;
-            dlpd = -(rcpd + lpd * dtpd) / tpd; dlmd = -(rcmd + lmd * dtmd) / tmd;
+            dlpd = -(rcpd + lpd * dtpd) * itpd; dlmd = -(rcmd + lmd * dtmd) * itmd;
             if (!valid) { dtpu = 0; dtmu = 0; dlpu = 0; dlmu = 0; }
             if (!validd) { dtpd = 0; dtmd = 0; dlpd = 0; dlmd = 0; }
-            double al = 1.0;
-            if (dtpu < 0) al = fmin(al, -tpu / dtpu);
-            if (dtmu < 0) al = fmin(al, -tmu / dtmu);
-            if (dlpu < 0) al = fmin(al, -lpu / dlpu);
-            if (dlmu < 0) al = fmin(al, -lmu / dlmu);
-            if (dtpd < 0) al = fmin(al, -tpd / dtpd);
-            if (dtmd < 0) al = fmin(al, -tmd / dtmd);
-            if (dlpd < 0) al = fmin(al, -lpd / dlpd);
-            if (dlmd < 0) al = fmin(al, -lmd / dlmd);
-            alpha = wave_min(al);
+            // largest step keeping every slack and multiplier positive: 1 / max(1, max_i(-d_i / v_i))
+            double rmax = fmax(fmax(-dtpu * itpu, -dtmu * itmu), fmax(-dlpu * ilpu, -dlmu * ilmu));
+            rmax = fmax(rmax, fmax(fmax(-dtpd * itpd, -dtmd * itmd), fmax(-dlpd * ilpd, -dlmd * ilmd)));
+            rmax = wave_max(rmax);
+            alpha = rmax > 1.0 ? fast_rcp(rmax) : 1.0;
             if (safe) break;
             if (pass == 0) {
                 const double mua = wave_sum((tpu + alpha * dtpu) * (lpu + alpha * dlpu) +
