@@ -61,6 +61,8 @@ typedef struct mpc_config {
     double eps_nl;       /* tyre-model denominator offset of the NL model (0.1)               */
     double sqp_tol;      /* SQP stop: largest change of an input in one iteration             */
     int sqp_max_iter;    /* SQP iteration cap per solve (status 1 when reached)               */
+    int ipm_cold_start;  /* 0 (default): closed-loop steps, and the SQP iterations of one NL solve, start the interior
+                          * point from the previous solve when that one hit a bound too; 1: always cold start */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

@@ -21,7 +21,7 @@ class MpcConfig(C.Structure):
         ("w", C.c_double * 7), ("We", C.c_double * 36), ("eps", C.c_double), ("tol_mu", C.c_double),
         ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
         ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
-        ("sqp_max_iter", C.c_int),
+        ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int),
     ]
 
 

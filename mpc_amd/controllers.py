@@ -77,7 +77,7 @@ class _CondensedMpc:
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
-                 _host_only: bool = False):
+                 ipm_warm_start: bool = True, _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
@@ -99,6 +99,7 @@ class _CondensedMpc:
         self.W, self.W_e = self._cost_matrices()
         self.batch = int(batch)
         self._tol = (tol_mu, tol_res, max_iter)
+        self._ipm_cold = 0 if ipm_warm_start else 1
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
             self.device = None
             self.solver = None
@@ -157,6 +158,7 @@ class _CondensedMpc:
         cfg.eps = 0.001
         cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
         cfg.lpv_lin_prev = 0
+        cfg.ipm_cold_start = self._ipm_cold
         return cfg
 
     def stability(self):
@@ -370,6 +372,7 @@ class NLOcp(_CondensedMpc):
         cfg.eps_nl = 0.1                                                             # NLMPC.py:116-126
         cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
         cfg.sqp_tol, cfg.sqp_max_iter = self._sqp
+        cfg.ipm_cold_start = self._ipm_cold
         return cfg
 
     def stability(self):

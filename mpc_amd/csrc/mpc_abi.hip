@@ -11,6 +11,7 @@ struct mpc_handle {
     mpc::DevCfg dev;
     double *Hws = nullptr;       // B * N * N condensed Hessians
     int *sqp = nullptr;          // B SQP iteration counts of the last NL call
+    double *ipm_ws = nullptr;    // B interior-point warm-start records (NULL: cold starts only)
     double *stat = nullptr;      // B * 4 solver records
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     double *mp_scen = nullptr;   // optional B * 6
@@ -78,6 +79,10 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
+    if (e == hipSuccess && !cfg->ipm_cold_start) {
+        e = hipMalloc(&h->ipm_ws, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(h->ipm_ws, 0, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
+    }
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
@@ -94,7 +99,7 @@ void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
-    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->sqp);
+    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     delete h;
 }
@@ -165,7 +170,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     if (h->cfg.kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_solve_only: NL needs lin_u (the SQP iterate)");
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
-    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.U_out = U_out; a.traj_out = traj_out;
+    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);
@@ -205,7 +210,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
     a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist; a.nx_plant = 8;
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
-    a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws;
+    a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
@@ -229,7 +234,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     a.state = state10; a.target_vel = target_vel; a.ekf_x = ekf_x; a.ekf_P = ekf_P; a.meas_noise = meas_noise;
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
-    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
+    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);

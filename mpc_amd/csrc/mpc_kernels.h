@@ -11,6 +11,8 @@
 
 namespace mpc {
 
+constexpr int IPM_WARM_DOUBLES = 6 * 64;   // interior-point warm-start record per scenario (see IpmParams)
+
 enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2, MODE_OFL = 3 };   // OFL: step planner on the EKF estimate
 
 struct DevCfg {
@@ -38,6 +40,7 @@ struct SolveArgs {
     double *lin_x, *lin_u;                                // LPV linearisation memory (updated)
     const double *mp_scen;                                // optional per-scenario model parameters
     double *Hws;                                          // workspace: B * N * N condensed Hessians
+    double *ipm_ws;                                       // workspace: B * IPM_WARM_DOUBLES interior-point warm-start records (or NULL)
     double *U_out, *traj_out, *u0_out, *wp_out;
     int *status_out, *iters_out;
     int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)

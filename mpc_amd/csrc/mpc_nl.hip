@@ -153,6 +153,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
     const PlantCoef pc = plant_coef(mp, plant[4]);             // constant over the launch: x[4] has zero derivative
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     double U = valid ? a.lin_u[(size_t)s * N + lane] : 0.0;    // SQP iterate, carried from call to call
+    double *warm_rec = a.ipm_ws ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
+    bool warm_ok = warm_rec && a.mode != MODE_SOLVE && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
@@ -338,11 +340,16 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
             if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
             if (!__all(ok)) {
                 nconstr++;
-                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
+                // start from the previous QP's interior-point solve: the previous SQP iteration's, or the previous
+                // closed-loop step's moved one stage ahead
+                const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
+                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm};
                 const IpmResult r = interior_point<N>(prm, lane, Hw, gq, up_d, lo_d);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
-            }
+                warm_ok = (warm_rec != nullptr) && r.status == 0;
+            } else
+                warm_ok = false;
             const double step = wave_max(valid ? fabs(Un - U) : 0.0);
             U = valid ? Un : 0.0;
             sqp++;
@@ -375,6 +382,7 @@ __global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const Solv
     }
 
     if (valid) a.lin_u[(size_t)s * N + lane] = U;
+    if (warm_rec && lane == 0) warm_rec[5 * WAVE] = (warm_ok && a.mode != MODE_SOLVE) ? 1.0 : 0.0;
     if (a.mode != MODE_SOLVE) {
         if (lane < 8) {
             double val = plant[0];

@@ -193,6 +193,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
     // increments of the waypoints (sequentially accumulated like np.cumsum)
     const PlantCoef pc = plant_coef(mp, plant[4]);
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
+    double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
+    bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
@@ -335,10 +337,13 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
             else constrained = 1;
         }
         if (constrained) {
-            const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter};
+            // closed loops start the interior point from the previous step's solve when that step needed one too
+            const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0};
             const IpmResult r = interior_point<N>(prm, lane, Hm, g, up_d, lo_d);
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
-        }
+            warm_ok = (warm_rec != nullptr) && r.status == 0;
+        } else
+            warm_ok = false;
         if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible
 
         // ------------------------------------------------------------ 5. outputs, prediction, plant
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
         }
     }
     if (lane == 0) {
+        if (warm_rec) warm_rec[5 * WAVE] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
         if (a.status_out) a.status_out[s] = status_max;
         if (a.iters_out) a.iters_out[s] = iters_tot;
