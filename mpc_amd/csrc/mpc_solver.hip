@@ -339,7 +339,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
         if (constrained) {
             // closed loops start the interior point from the previous step's solve when that step needed one too
             const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0};
-            const IpmResult r = interior_point<N>(prm, lane, Hm, g, up_d, lo_d);
+            const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d);
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
             warm_ok = (warm_rec != nullptr) && r.status == 0;
         } else
