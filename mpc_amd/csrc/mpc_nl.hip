@@ -114,7 +114,7 @@ __device__ __forceinline__ void nl_linearise(const double *x, double u, double h
 }
 
 template <int N>
-__global__ __launch_bounds__(WAVE, 1) void k_mpc_nl(const DevCfg cfg, const SolveArgs a)
+__global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const SolveArgs a)
 {
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
