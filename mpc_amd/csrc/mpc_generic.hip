@@ -62,35 +62,76 @@ template <int R> __device__ __forceinline__ double vmaxabs(const Vec<R> &x)
 }
 
 // LDL' of the symmetric matrix whose lower triangle sits in M (column-major with leading dimension LD: entry (row i,
-// column j) at M[j*LD + i], i >= j).  Column k keeps c(i,k) = d(k) l(i,k); the factor mirrors it into the upper
-// triangle (M[i*LD + k]... stored as column i, row k) so that the backward substitution also reads thread-contiguously.
+// column j) at M[j*LD + i], i >= j).  Column k keeps c(i,k) = d(k) l(i,k) with d(k) on the diagonal; the factor mirrors
+// it into the upper triangle (column i, row k) so that the backward substitution also reads thread-contiguously.
+// Left-looking in blocks of LDLW columns held in registers: every earlier pivot column is read from LDS once per block
+// (one coalesced read per lane plus LDLW broadcast reads for LDLW * R updates) instead of one read-modify-write of LDS
+// per updated entry.  s_dinv receives the reciprocal pivots.
+constexpr int LDLW = 8;
+
 template <int R>
-__device__ __forceinline__ void lds_factor(double *M, int LD, int N, int lane, double (&dinv)[R])
+__device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, int N, int lane, double (&dinv)[R])
 {
 #pragma unroll
     for (int q = 0; q < R; q++) dinv[q] = 1.0;
-    for (int k = 0; k < N; k++) {
-        const double inv = fast_rcp(M[k * LD + k]);
-        double l[R], c[R];
+#pragma unroll 1
+    for (int jb = 0; jb < N; jb += LDLW) {
+        double a[LDLW][R];
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = lane + WAVE * q;
-            c[q] = (i > k && i < N) ? M[k * LD + i] : 0.0;
-            l[q] = c[q] * inv;
-            if (i == k) dinv[q] = inv;
+        for (int w = 0; w < LDLW; w++) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q, j = jb + w;
+                a[w][q] = (j < N && i >= j && i < N) ? M[j * LD + i] : 0.0;
+            }
         }
-        for (int j = k + 1; j < N; j++) {
-            const double cj = M[k * LD + j];           // wave-uniform address: LDS broadcast
+#pragma unroll 1
+        for (int k = 0; k < jb; k++) {
+            const double ik = s_dinv[k];
+            double li[R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int i = lane + WAVE * q;
-                if (i >= j && i < N) M[j * LD + i] = fma(-l[q], cj, M[j * LD + i]);
+                li[q] = (i >= jb && i < N) ? M[k * LD + i] * ik : 0.0;
+            }
+#pragma unroll
+            for (int w = 0; w < LDLW; w++) {
+                const double cjk = (jb + w < N) ? M[k * LD + jb + w] : 0.0;    // wave-uniform address: LDS broadcast
+#pragma unroll
+                for (int q = 0; q < R; q++) a[w][q] = fma(-li[q], cjk, a[w][q]);
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = lane + WAVE * q;
-            if (i > k && i < N) M[i * LD + k] = c[q];   // mirror: column i, row k
+        for (int w = 0; w < LDLW; w++) {
+            const int k = jb + w;
+            if (k < N) {
+                const double pivot = (R == 1 || k < WAVE) ? rl(a[w][0], k & (WAVE - 1)) : rl(a[w][R - 1], k - WAVE);
+                const double inv = fast_rcp(pivot);
+                double c[R], l[R];
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int i = lane + WAVE * q;
+                    c[q] = (i > k && i < N) ? a[w][q] : 0.0;
+                    l[q] = c[q] * inv;
+                    if (i == k) dinv[q] = inv;
+                }
+#pragma unroll
+                for (int w2 = w + 1; w2 < LDLW; w2++) {
+                    const int j = jb + w2;
+                    if (j < N) {
+                        const double cjk = (R == 1 || j < WAVE) ? rl(c[0], j & (WAVE - 1)) : rl(c[R - 1], j - WAVE);
+#pragma unroll
+                        for (int q = 0; q < R; q++) a[w2][q] = fma(-l[q], cjk, a[w2][q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int i = lane + WAVE * q;
+                    if (i == k) M[k * LD + k] = pivot;
+                    if (i > k && i < N) { M[k * LD + i] = c[q]; M[i * LD + k] = c[q]; }   // column k and its mirror
+                }
+                if (lane == 0) s_dinv[k] = inv;
+            }
         }
         wave_sync();
     }
@@ -134,7 +175,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     const int LD = N | 1;                 // odd leading dimension: the one strided access per pivot is 2-way at worst
     extern __shared__ double lds[];
     double *s_ref = lds, *s_p = s_ref + 3 * (N + 1), *s_stage = s_p + (N + 1), *s_wv = s_stage + N * STAGE_W;
-    double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_ekf = M + (size_t)N * LD;
+    double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_dinv = M + (size_t)N * LD, *s_ekf = s_dinv + N;
     if (lane < 36) s_We[lane] = cfg.We[lane];
 
     ModelParams mp;
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
         for (int q = 0; q < R; q++) steer_bounds(xh5, dmax, umax, dt, lane + WAVE * q, up_d[q], lo_d[q], relaxed);
         double dinv[R];
-        lds_factor<R>(M, LD, N, lane, dinv);
+        lds_factor<R>(M, s_dinv, LD, N, lane, dinv);
         Vec<R> U;
         int iters = 0, status = 0, constrained = 0;
         {
@@ -421,7 +462,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                     }
                 }
                 wave_sync();
-                lds_factor<R>(M, LD, N, lane, dinv);
+                lds_factor<R>(M, s_dinv, LD, N, lane, dinv);
                 Vec<R> dU, dtpu, dtmu, dlpu, dlmu, dtpd, dtmd, dlpd, dlmd;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
@@ -616,7 +657,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 static size_t any_lds_bytes(int N, int mode)
 {
     const int LD = N | 1;
-    return sizeof(double) * ((size_t)4 * (N + 1) + (size_t)N * STAGE_W + 6 * (size_t)N + 36 + (size_t)N * LD +
+    return sizeof(double) * ((size_t)4 * (N + 1) + (size_t)N * STAGE_W + 6 * (size_t)N + 36 + (size_t)N * LD + (size_t)N +
                              (mode == MODE_OFL ? EKF_LDS : 0));
 }
 
