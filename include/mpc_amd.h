@@ -75,6 +75,12 @@ const char *mpc_last_error(const mpc_handle *h); /* h may be NULL: last error of
 /* Optional per-scenario model parameters mp[B][6] (tyre / mass sweeps); NULL restores cfg.mp. */
 int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario);
 
+/* Optional per-scenario cost weights cost[B][43] (device): diag of W (7 entries, as cfg.w) followed by W_e (6x6
+ * row-major, as cfg.We), for tuning sweeps where every scenario is one point of the sweep (plot_generator.py:168-515
+ * rewrites parameters_*.yaml and rebuilds the controller per point); NULL restores cfg.w / cfg.We.  Scenarios are then
+ * condensed individually (the fixed-model cache is bypassed).  Not for MPC_KIND_NL, whose weights are hard-coded. */
+int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario);
+
 /* Fixed-model cache for the linear controllers (kind L / OFL): condenses the horizon once for "every stage at
  * speed vx" (the skidpad planner hands the controller a constant speed profile, path_planning.py:238-240) and
  * caches H and inv(H) times every way the gradient depends on the step's data.  Scenarios whose speed profile

@@ -32,6 +32,7 @@ _SIGS = {
     "mpc_destroy": ([_vp], None),
     "mpc_last_error": ([_vp], C.c_char_p),
     "mpc_set_model_params": ([_vp, _vp], C.c_int),
+    "mpc_set_cost_weights": ([_vp, _vp], C.c_int),
     "mpc_condense_fixed": ([_vp, _vp, C.c_double, C.c_int], C.c_int),
     "mpc_solve_only": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
     "mpc_closed_loop_step": ([_vp, _vp, C.c_int, C.c_int] + [_vp] * 12, C.c_int),

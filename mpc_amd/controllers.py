@@ -248,6 +248,21 @@ class _CondensedMpc:
             rc = self.solver._lib.mpc_set_model_params(self.solver.h, _dev.ptr(mp))
         _lib.check(rc, self.solver.h, "mpc_set_model_params")
 
+    def set_cost_weights(self, w_per_scenario, We_per_scenario):
+        """Per-scenario cost for tuning sweeps: w (batch, 7) = diag(W), We (batch, 6, 6) terminal weight on the 6 states;
+        (None, None) restores the weights of the yaml file.  Scenarios are then condensed individually."""
+        if w_per_scenario is None:
+            rc = self.solver._lib.mpc_set_cost_weights(self.solver.h, None)
+        else:
+            w = np.asarray(w_per_scenario, dtype=np.float64).reshape(self.batch, 7)
+            We = np.asarray(We_per_scenario, dtype=np.float64).reshape(self.batch, 36)
+            if np.any(w[:, 6] <= 0):
+                raise ValueError("the input weight must be positive in every scenario")
+            cost = _dev.f64(np.ascontiguousarray(np.hstack([w, We])), self.device)
+            torch.cuda.synchronize(self.device)
+            rc = self.solver._lib.mpc_set_cost_weights(self.solver.h, _dev.ptr(cost))
+        _lib.check(rc, self.solver.h, "mpc_set_cost_weights")
+
     def condense_fixed(self, vx, exclusive: bool = False):
         """Cache the condensed problem for a constant speed profile (None switches the cache off).  With
         `exclusive` the caller promises that every scenario runs at vx (status 3 flags a broken promise)."""

@@ -15,6 +15,7 @@ struct mpc_handle {
     double *stat = nullptr;      // B * 4 solver records
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     double *mp_scen = nullptr;   // optional B * 6
+    double *cost_scen = nullptr; // optional B * 43 per-scenario cost weights
     double *stats16 = nullptr;   // device result of the statistics reduction
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double sh_vx = 0.0;
@@ -99,7 +100,7 @@ void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
-    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
+    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     delete h;
 }
@@ -111,6 +112,17 @@ int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
     const size_t bytes = (size_t)h->cfg.B * 6 * sizeof(double);
     if (!h->mp_scen) HIP_TRY(h, hipMalloc(&h->mp_scen, bytes));
     HIP_TRY(h, hipMemcpy(h->mp_scen, mp_per_scenario, bytes, hipMemcpyDeviceToDevice));
+    return MPC_OK;
+}
+
+int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario)
+{
+    if (!h) return MPC_EINVAL;
+    if (h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_set_cost_weights: the NL controller's weights are fixed by its definition");
+    if (!cost_per_scenario) { (void)hipFree(h->cost_scen); h->cost_scen = nullptr; return MPC_OK; }
+    const size_t bytes = (size_t)h->cfg.B * 43 * sizeof(double);
+    if (!h->cost_scen) HIP_TRY(h, hipMalloc(&h->cost_scen, bytes));
+    HIP_TRY(h, hipMemcpy(h->cost_scen, cost_per_scenario, bytes, hipMemcpyDeviceToDevice));
     return MPC_OK;
 }
 
@@ -142,7 +154,7 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
 
 static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
 {
-    if (h->sh_on && !h->mp_scen) {
+    if (h->sh_on && !h->mp_scen && !h->cost_scen) {
         a.sh_H = h->sh_H; a.sh_Kref = h->sh_Kref; a.sh_Kx = h->sh_Kx; a.sh_vx = h->sh_vx; a.sh_mask = h->sh_mask; a.sh_exclusive = h->sh_exclusive ? 1 : 0;
     }
 }
@@ -170,7 +182,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     if (h->cfg.kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_solve_only: NL needs lin_u (the SQP iterate)");
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
-    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
+    a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);
@@ -210,7 +222,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
     a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist; a.nx_plant = 8;
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
-    a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
+    a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
@@ -234,7 +246,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     a.state = state10; a.target_vel = target_vel; a.ekf_x = ekf_x; a.ekf_P = ekf_P; a.meas_noise = meas_noise;
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
-    a.mp_scen = h->mp_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
+    a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);

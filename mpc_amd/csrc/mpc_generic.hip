@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     extern __shared__ double lds[];
     double *s_ref = lds, *s_p = s_ref + 3 * (N + 1), *s_stage = s_p + (N + 1), *s_wv = s_stage + N * STAGE_W;
     double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_dinv = M + (size_t)N * LD, *s_ekf = s_dinv + N;
-    if (lane < 36) s_We[lane] = cfg.We[lane];
+    if (lane < 36) s_We[lane] = a.cost_scen ? a.cost_scen[43 * (size_t)s + 7 + lane] : cfg.We[lane];
 
     ModelParams mp;
     if (a.mp_scen) {
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     const double f35 = dt * (-mp.Cf / mp.m), f45 = dt * (-mp.lf * mp.Cf / mp.Iz);
     double wq[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];
-    const double wr = dt * cfg.w[6];
+    for (int c = 0; c < 6; c++) wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);
+    const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
     bool valid[R], validd[R];
 #pragma unroll
     for (int q = 0; q < R; q++) { valid[q] = lane + WAVE * q < N; validd[q] = lane + WAVE * q < N - 1; }

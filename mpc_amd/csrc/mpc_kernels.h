@@ -39,6 +39,7 @@ struct SolveArgs {
     const double *target_vel;
     double *lin_x, *lin_u;                                // LPV linearisation memory (updated)
     const double *mp_scen;                                // optional per-scenario model parameters
+    const double *cost_scen;                              // optional per-scenario cost [B][43]: diag W (7), then W_e (6x6)
     double *Hws;                                          // workspace: B * N * N condensed Hessians
     double *ipm_ws;                                       // workspace: B * IPM_WARM_DOUBLES interior-point warm-start records (or NULL)
     double *U_out, *traj_out, *u0_out, *wp_out;

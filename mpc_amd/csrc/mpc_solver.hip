@@ -147,7 +147,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
     if (GENERAL) {
-        if (lane < 36) s_We[lane] = cfg.We[lane];
+        if (lane < 36) s_We[lane] = a.cost_scen ? a.cost_scen[43 * (size_t)blockIdx.x + 7 + lane] : cfg.We[lane];
     } else {
         int ci = 0;
 #pragma unroll
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2)
             Newton<N> nt;
             double wq[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) wq[c] = dt * cfg.w[c];   // acados scales stage costs by the time step
+            for (int c = 0; c < 6; c++) wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);   // acados scales stage costs by the time step
             double xf[1][6] = {{0, 0, 0, xh3, xh4, xh5}};
             const double c01s[1] = {1.0}, c3s[1] = {c3};
             double gs[1] = {0.0};
             condense<N, 1>(cfg, lane, s_stage, s_ref, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
             g = gs[0];
-            const double wr = dt * cfg.w[6];
+            const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 if (i == lane) nt.row[i] += wr;
