@@ -125,7 +125,7 @@ template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STA
 constexpr int FIXED_WPB = 4;
 
 template <int N, bool GENERAL>
-__global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, GENERAL ? 1 : 2) void k_mpc(const DevCfg cfg,
+__global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(const DevCfg cfg,
                                                                                           const SolveArgs a)
 {
     constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
