@@ -665,22 +665,12 @@ hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 {
     if (cfg.N < 2 || cfg.N > MPC_MAX_HORIZON) return hipErrorInvalidValue;
     const size_t lds = any_lds_bytes(cfg.N, a.mode);
-    static bool attr1 = false, attr2 = false;
+    static bool lds_ok1[MPC_MAX_DEVICES] = {}, lds_ok2[MPC_MAX_DEVICES] = {};
     if (cfg.N <= WAVE) {
-        if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc_any<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr1 = true;
-        }
+        if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_mpc_any<1>), lds_ok1)) return e;
         hipLaunchKernelGGL(k_mpc_any<1>, dim3(a.B), dim3(WAVE), lds, st, cfg, a);
     } else {
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc_any<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
+        if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_mpc_any<2>), lds_ok2)) return e;
         hipLaunchKernelGGL(k_mpc_any<2>, dim3(a.B), dim3(WAVE), lds, st, cfg, a);
     }
     return hipGetLastError();

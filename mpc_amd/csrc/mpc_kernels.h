@@ -55,6 +55,20 @@ struct SolveArgs {
     int sh_mask;             // bit c set: reference component c (x, y, sin psi) carries weight
 };
 
+// Raises a kernel's dynamic-LDS limit to the CU's 160 KB once per device and kernel (`done` is that kernel's flag table).
+constexpr int MPC_MAX_DEVICES = 64;
+inline hipError_t allow_big_lds(const void *kernel, bool (&done)[MPC_MAX_DEVICES])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MPC_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
 hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);    // MPC_KIND_NL, horizons of MPC_HORIZONS
 hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);   // run-time horizon, no cache

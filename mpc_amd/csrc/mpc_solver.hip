@@ -518,13 +518,8 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         const int ncomp = __builtin_popcount(a.sh_mask & 7);
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
         const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_area);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mpc<N, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        static bool lds_ok[MPC_MAX_DEVICES] = {};
+        if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false>), lds_ok)) return e;
         hipLaunchKernelGGL((k_mpc<N, false>), dim3((a.B + FIXED_WPB - 1) / FIXED_WPB), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
