@@ -151,6 +151,24 @@ int mpc_ekf_measurement_update(void *stream, int B, const double *r_diag_host, d
 int mpc_ekf_kalman_gain(void *stream, int B, const double *r_diag_host, const double *P, double *K_out);
 int mpc_ekf_jacobian(void *stream, int B, double dt, const double *mp6_host, const double *x, double *F);
 
+/* StepSimulator.dlqr_sim (simulator.py:378-428), nsteps per launch: the saturated LQR baseline u = K (ref - x[[1,3,5,6,7]])
+ * with ref = (1/500, 0, 0, 0, 0), clipped to +-rate_limit and then to what keeps the last state entry within
+ * +-angle_limit over one dt, followed by the RK4 plant step.  x [B][nx] (nx = 8 or 10, updated); K_host is a host
+ * array of 5 (the DARE gain of the L controller, LMPC2.py:433-440), or K_per_scenario [B][5] on the device for gain
+ * sweeps (takes precedence); u_hist [nsteps][B] and x_hist [nsteps][B][nx] optional. */
+int mpc_dlqr_run(void *stream, int B, int nx, int nsteps, double dt, const double *mp6_host, const double *K_host,
+                 const double *K_per_scenario, double rate_limit, double angle_limit, double *x, double *u_hist,
+                 double *x_hist);
+
+/* StepSimulator.lsim (simulator.py:334-376), nsteps per launch: an open-loop input sequence through the 10-state plant
+ * and the EKF (time update with the same input, measurement update on the measured entries of the new plant state,
+ * + meas_noise[nsteps][B][7] if given).  u is [nsteps] (device) shared by all scenarios, or [nsteps][B] when
+ * u_per_scenario != 0; state10 [B][10], ekf_x [B][10], ekf_P [B][10][10] are updated; x_hist / est_hist
+ * [nsteps][B][10] optional. */
+int mpc_lsim_run(void *stream, int B, int nsteps, double dt, const double *mp6_host, const double *q_diag_host,
+                 const double *r_diag_host, const double *u, int u_per_scenario, const double *meas_noise, double *state10,
+                 double *ekf_x, double *ekf_P, double *x_hist, double *est_hist);
+
 /* SkidpadPlanner.request_waypoints (utils/path_planning.py:220-261, laps 0..7) and
  * StepPlanner.request_waypoints (utils/step_planning.py:88-117): pose [B][3] = x, y, heading;
  * wp_out [B][N+1][4]; progress_out [B]; abs_out [B][N+1][4] (step planner, may be NULL). */

@@ -44,6 +44,8 @@ _SIGS = {
     "mpc_ekf_measurement_update": ([_vp, C.c_int, _dp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_ekf_kalman_gain": ([_vp, C.c_int, _dp, _vp, _vp], C.c_int),
     "mpc_ekf_jacobian": ([_vp, C.c_int, C.c_double, _dp, _vp, _vp], C.c_int),
+    "mpc_dlqr_run": ([_vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _vp, C.c_double, C.c_double, _vp, _vp, _vp], C.c_int),
+    "mpc_lsim_run": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_plan_skidpad": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),

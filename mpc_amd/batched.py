@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 from . import _dev, _lib
-from .controllers import LOcp, LPVOcp, NLOcp, OFLOcp
+from .continuous_dynamics import Dynamics
+from .controllers import LOcp, LPVOcp, NLOcp, OFLOcp, read_parameters
 from .EKF import P0_DIAG, Q_DIAG
 
 
@@ -122,7 +123,7 @@ class StepOFLBatch:
         if fixed_model_cache and np.all(tv == tv[0]):
             self.ocp.condense_fixed(float(tv[0]), exclusive=True)
         self._qd = np.ascontiguousarray(Q_DIAG, dtype=np.float64)
-        self._rd = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])             # R = diag(sigma) (EKF.py:32)
+        self._rd = R_DIAG.copy()
         self.u0 = torch.zeros(B, dtype=torch.float64, device=dev)
         self.status = torch.zeros(B, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -143,3 +144,87 @@ class StepOFLBatch:
             _dev.ptr(self.u0), _dev.ptr(us), _dev.ptr(xs), _dev.ptr(es), _dev.ptr(self.status), _dev.ptr(self.iters))
         _lib.check(rc, s.h, "mpc_ofl_closed_loop_run")
         return (xs, us, es) if record else None
+
+
+R_DIAG = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])             # R = diag(sigma) (EKF.py:32)
+
+
+class StepLQRBatch:
+    """Batched saturated-LQR baseline (StepSimulator.dlqr_sim, simulator.py:378-428): B scenarios, each with its own
+    plant state and, optionally, its own gain (K of shape (B, 5)); one launch advances every scenario by n steps.  The
+    limits are those of parameters_NL.yaml, as in the reference."""
+
+    def __init__(self, dt, starting_states, K, device=None, params: dict | None = None):
+        x = np.ascontiguousarray(starting_states, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] not in (8, 10):
+            raise ValueError("starting_states must be (B, 8) or (B, 10)")
+        self.B, self.nx = x.shape
+        self.dt = float(dt)
+        self.dynamics = Dynamics(self.dt, disturbance=self.nx == 10, device=device)
+        dev = self.device = self.dynamics.device
+        self.state = _dev.f64(x, dev).clone()
+        K = np.asarray(K, dtype=np.float64)
+        if K.size == 5:
+            self._K, self._K_scen = np.ascontiguousarray(K.reshape(5)), None
+        elif K.shape == (self.B, 5):
+            self._K, self._K_scen = None, _dev.f64(np.ascontiguousarray(K), dev)
+        else:
+            raise ValueError("K must hold 5 gains, or (B, 5) for one gain per scenario")
+        limits = read_parameters("parameters_NL.yaml", params)["model"]
+        self.rate_limit = float(limits["max_steering_rate"])
+        self.angle_limit = float(limits["max_steering_angle"])
+
+    def run(self, n_steps: int, record: bool = True):
+        """Returns (states (n, B, nx), inputs (n, B)) as device tensors when record is set."""
+        dev = self.device
+        xs = torch.empty((n_steps, self.B, self.nx), dtype=torch.float64, device=dev) if record else None
+        us = torch.empty((n_steps, self.B), dtype=torch.float64, device=dev) if record else None
+        lib = self.dynamics._lib
+        rc = lib.mpc_dlqr_run(_dev.stream_ptr(dev), self.B, self.nx, int(n_steps), self.dt, _lib.hptr(self.dynamics._mp),
+                              _lib.hptr(self._K) if self._K is not None else None, _dev.ptr(self._K_scen),
+                              self.rate_limit, self.angle_limit, _dev.ptr(self.state), _dev.ptr(us), _dev.ptr(xs))
+        _lib.check(rc, None, "mpc_dlqr_run")
+        return (xs, us) if record else None
+
+
+class LsimBatch:
+    """Batched open-loop response with the EKF in the loop (StepSimulator.lsim, simulator.py:334-376): B scenarios, each
+    with its own true 10-state plant, estimate and covariance; the input sequence is shared ((n,)) or per scenario
+    ((n, B))."""
+
+    def __init__(self, dt, true_states, estimates=None, device=None):
+        x = np.ascontiguousarray(true_states, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != 10:
+            raise ValueError("true_states must be (B, 10)")
+        self.B = B = x.shape[0]
+        self.dt = float(dt)
+        self.dynamics = Dynamics(self.dt, disturbance=True, device=device)
+        dev = self.device = self.dynamics.device
+        self.state = _dev.f64(x, dev).clone()
+        if estimates is None:                       # simulator.py:342-353
+            estimates = np.tile(np.array([0.0, 0.0, 1.0, 0.0, 8.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (B, 1))
+        self.estimate = _dev.f64(np.ascontiguousarray(estimates, dtype=np.float64), dev).clone()
+        self.P = _dev.f64(np.tile(np.diag(P0_DIAG), (B, 1, 1)), dev).clone()
+        self._qd = np.ascontiguousarray(Q_DIAG, dtype=np.float64)
+        self._rd = R_DIAG.copy()
+
+    def run(self, u, n_steps: int | None = None, meas_noise=None):
+        """u: a float (held for n_steps), (n,) or (n, B).  Returns (states, estimates), both (n, B, 10) device tensors."""
+        dev = self.device
+        if np.isscalar(u):
+            u = np.full(int(n_steps), float(u))
+        u = _dev.f64(np.ascontiguousarray(u, dtype=np.float64), dev) if not torch.is_tensor(u) else u.contiguous()
+        n = int(u.shape[0]) if n_steps is None else int(n_steps)
+        if u.ndim not in (1, 2) or u.shape[0] < n or (u.ndim == 2 and u.shape[1] != self.B):
+            raise ValueError("u must be a float, (n_steps,) or (n_steps, B)")
+        noise = _dev.f64(meas_noise, dev) if meas_noise is not None else None
+        if noise is not None and tuple(noise.shape) != (n, self.B, 7):
+            raise ValueError("meas_noise must be (n_steps, B, 7)")
+        xs = torch.empty((n, self.B, 10), dtype=torch.float64, device=dev)
+        es = torch.empty((n, self.B, 10), dtype=torch.float64, device=dev)
+        rc = self.dynamics._lib.mpc_lsim_run(
+            _dev.stream_ptr(dev), self.B, n, self.dt, _lib.hptr(self.dynamics._mp), _lib.hptr(self._qd), _lib.hptr(self._rd),
+            _dev.ptr(u), int(u.ndim == 2), _dev.ptr(noise), _dev.ptr(self.state), _dev.ptr(self.estimate), _dev.ptr(self.P),
+            _dev.ptr(xs), _dev.ptr(es))
+        _lib.check(rc, None, "mpc_lsim_run")
+        return xs, es

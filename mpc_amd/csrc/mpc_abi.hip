@@ -315,6 +315,28 @@ int mpc_ekf_jacobian(void *stream, int B, double dt, const double *mp6_host, con
     return MPC_OK;
 }
 
+int mpc_dlqr_run(void *stream, int B, int nx, int nsteps, double dt, const double *mp6_host, const double *K_host,
+                 const double *K_per_scenario, double rate_limit, double angle_limit, double *x, double *u_hist,
+                 double *x_hist)
+{
+    if (B < 1 || (nx != 8 && nx != 10) || nsteps < 1 || !(dt > 0.0) || !mp6_host || (!K_host && !K_per_scenario) || !x)
+        return fail(nullptr, MPC_EINVAL, "mpc_dlqr_run: bad argument");
+    AUX_TRY(mpc::launch_dlqr_run((hipStream_t)stream, B, nx, nsteps, dt, mp6_host, K_host, K_per_scenario, rate_limit,
+                                 angle_limit, x, u_hist, x_hist));
+    return MPC_OK;
+}
+
+int mpc_lsim_run(void *stream, int B, int nsteps, double dt, const double *mp6_host, const double *q_diag_host,
+                 const double *r_diag_host, const double *u, int u_per_scenario, const double *meas_noise, double *state10,
+                 double *ekf_x, double *ekf_P, double *x_hist, double *est_hist)
+{
+    if (B < 1 || nsteps < 1 || !(dt > 0.0) || !mp6_host || !q_diag_host || !r_diag_host || !u || !state10 || !ekf_x || !ekf_P)
+        return fail(nullptr, MPC_EINVAL, "mpc_lsim_run: bad argument");
+    AUX_TRY(mpc::launch_lsim_run((hipStream_t)stream, B, nsteps, dt, mp6_host, q_diag_host, r_diag_host, u, u_per_scenario,
+                                 meas_noise, state10, ekf_x, ekf_P, x_hist, est_hist));
+    return MPC_OK;
+}
+
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out)
 {

@@ -79,20 +79,16 @@ __global__ __launch_bounds__(64) void k_ekf_jacobian(int B, double dt, MP6 m, co
 
 // EKF.py:38-43: x <- x + dt f(x,u) (forward Euler), F at the pre-update estimate, P <- F P F' + Q.
 // F is sparse (rows 0-3, 5, 6 carry off-diagonal terms); the products below only visit its pattern.
-__global__ __launch_bounds__(64) void k_ekf_time_update(int B, double dt, MP6 m, V10 qd, double *x, double *P,
-                                                        const double *u)
+__device__ __forceinline__ void ekf_time_update_one(double dt, const ModelParams &mp, const V10 &qd, double *xg, double *Pg,
+                                                    double u)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B) return;
-    const ModelParams mp = to_mp(m);
     double xs[10], xd[10], F[100];
 #pragma unroll
-    for (int i = 0; i < 10; i++) xs[i] = x[(size_t)s * 10 + i];
-    plant_f<10>(xs, u[s], mp, xd);
+    for (int i = 0; i < 10; i++) xs[i] = xg[i];
+    plant_f<10>(xs, u, mp, xd);
     ekf_jacobian(xs, dt, mp, F);
 #pragma unroll
-    for (int i = 0; i < 10; i++) x[(size_t)s * 10 + i] = xd[i] * dt + xs[i];
-    double *Pg = P + (size_t)s * 100;
+    for (int i = 0; i < 10; i++) xg[i] = xd[i] * dt + xs[i];
     double T[100];
     for (int i = 0; i < 10; i++)
         for (int j = 0; j < 10; j++) {
@@ -108,17 +104,21 @@ __global__ __launch_bounds__(64) void k_ekf_time_update(int B, double dt, MP6 m,
         }
 }
 
+__global__ __launch_bounds__(64) void k_ekf_time_update(int B, double dt, MP6 m, V10 qd, double *x, double *P,
+                                                        const double *u)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    ekf_time_update_one(dt, to_mp(m), qd, x + (size_t)s * 10, P + (size_t)s * 100, u[s]);
+}
+
 __constant__ int c_meas_idx[7] = {0, 1, 2, 3, 4, 6, 7};   // continuous_dynamics.py:35-45
 
 // EKF.py:45-49,65-74: K = solve(S', (P H')')' with S = H P H' + R, x += K (y - H x), P -= K H P.
 // The 7x7 system is solved by Gaussian elimination with partial pivoting (what numpy.linalg.solve does).
-__global__ __launch_bounds__(64) void k_ekf_meas_update(int B, V7 rd, double *x, double *P, const double *y, double *K_out,
-                                                        int gain_only)
+__device__ __forceinline__ void ekf_meas_update_one(const V7 &rd, double *xg, double *Pg, const double *y, double *K_out,
+                                                    int gain_only)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B) return;
-    double *Pg = P + (size_t)s * 100;
-    double *xg = x + (size_t)s * 10;
     double M[49], X[70];
     for (int a = 0; a < 7; a++)
         for (int b = 0; b < 7; b++)   // M = S'
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(64) void k_ekf_meas_update(int B, V7 rd, double *x,
     // K[i][a] = X[a][i]
     if (K_out)
         for (int i = 0; i < 10; i++)
-            for (int a = 0; a < 7; a++) K_out[(size_t)s * 70 + i * 7 + a] = X[a * 10 + i];
+            for (int a = 0; a < 7; a++) K_out[i * 7 + a] = X[a * 10 + i];
     if (gain_only) return;
     double innov[7];
-    for (int a = 0; a < 7; a++) innov[a] = y[(size_t)s * 7 + a] - xg[c_meas_idx[a]];
+    for (int a = 0; a < 7; a++) innov[a] = y[a] - xg[c_meas_idx[a]];
     for (int i = 0; i < 10; i++) {
         double acc = 0.0;
         for (int a = 0; a < 7; a++) acc += X[a * 10 + i] * innov[a];
@@ -166,6 +166,15 @@ __global__ __launch_bounds__(64) void k_ekf_meas_update(int B, V7 rd, double *x,
             for (int a = 0; a < 7; a++) acc += X[a * 10 + i] * HP[a * 10 + j];
             Pg[i * 10 + j] -= acc;
         }
+}
+
+__global__ __launch_bounds__(64) void k_ekf_meas_update(int B, V7 rd, double *x, double *P, const double *y, double *K_out,
+                                                        int gain_only)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    ekf_meas_update_one(rd, x ? x + (size_t)s * 10 : nullptr, P + (size_t)s * 100, y ? y + (size_t)s * 7 : nullptr,
+                        K_out ? K_out + (size_t)s * 70 : nullptr, gain_only);
 }
 
 static inline V10 v10_from_host(const double *p) { V10 m; for (int i = 0; i < 10; i++) m.v[i] = p[i]; return m; }
@@ -190,6 +199,101 @@ hipError_t launch_ekf_meas_update(hipStream_t st, int B, const double *rd, doubl
 hipError_t launch_ekf_jacobian(hipStream_t st, int B, double dt, const double *mp6, const double *x, double *F)
 {
     hipLaunchKernelGGL(k_ekf_jacobian, dim3((B + 63) / 64), dim3(64), 0, st, B, dt, mp6_from_host(mp6), x, F);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- baselines
+struct V5 { double v[5]; };
+
+// StepSimulator.dlqr_sim (simulator.py:378-428): nsteps of u = K (ref - x[[1,3,5,6,7]]) with ref = (1/500, 0, 0, 0, 0),
+// clipped to the rate limit and then to what keeps the LAST state entry inside the angle limit over one dt (the
+// reference reads full_state[-1]: the steering angle of the 8-state plant), followed by the RK4 plant step.
+template <int NX>
+__global__ __launch_bounds__(64) void k_dlqr_run(int B, int nsteps, double dt, MP6 m, V5 K, const double *K_scen,
+                                                 double rate_limit, double angle_limit, double *x, double *u_hist,
+                                                 double *x_hist)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    const ModelParams mp = to_mp(m);
+    const PlantCoef pc = plant_coef(mp, x[(size_t)s * NX + 4]);
+    double k[5], xs[NX];
+#pragma unroll
+    for (int i = 0; i < 5; i++) k[i] = K_scen ? K_scen[(size_t)s * 5 + i] : K.v[i];
+#pragma unroll
+    for (int i = 0; i < NX; i++) xs[i] = x[(size_t)s * NX + i];
+    for (int t = 0; t < nsteps; t++) {
+        double steer = k[0] * (1.0 / 500.0 - xs[1]) + k[1] * (0.0 - xs[3]) + k[2] * (0.0 - xs[5]) + k[3] * (0.0 - xs[6])
+                       + k[4] * (0.0 - xs[7]);
+        steer = fmin(fmax(steer, -rate_limit), rate_limit);
+        const double cur = xs[NX - 1];
+        steer = fmin(fmax(steer, (-angle_limit - cur) / dt), (angle_limit - cur) / dt);
+        plant_rk4_c<NX>(xs, steer, dt, pc);
+        if (u_hist) u_hist[(size_t)t * B + s] = steer;
+        if (x_hist)
+#pragma unroll
+            for (int i = 0; i < NX; i++) x_hist[((size_t)t * B + s) * NX + i] = xs[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++) x[(size_t)s * NX + i] = xs[i];
+}
+
+hipError_t launch_dlqr_run(hipStream_t st, int B, int nx, int nsteps, double dt, const double *mp6, const double *K5,
+                           const double *K_scen, double rate_limit, double angle_limit, double *x, double *u_hist,
+                           double *x_hist)
+{
+    V5 K; for (int i = 0; i < 5; i++) K.v[i] = K5 ? K5[i] : 0.0;
+    if (nx == 8)
+        hipLaunchKernelGGL(k_dlqr_run<8>, dim3((B + 63) / 64), dim3(64), 0, st, B, nsteps, dt, mp6_from_host(mp6), K, K_scen,
+                           rate_limit, angle_limit, x, u_hist, x_hist);
+    else if (nx == 10)
+        hipLaunchKernelGGL(k_dlqr_run<10>, dim3((B + 63) / 64), dim3(64), 0, st, B, nsteps, dt, mp6_from_host(mp6), K, K_scen,
+                           rate_limit, angle_limit, x, u_hist, x_hist);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// StepSimulator.lsim (simulator.py:334-376): an open-loop input sequence through the 10-state plant and the EKF
+// (time update with the same input, measurement update on the noiseless measurement of the new plant state, plus
+// meas_noise when given).  u is [nsteps] shared by all scenarios, or [nsteps][B] when u_per_scenario is set.
+__global__ __launch_bounds__(64) void k_lsim_run(int B, int nsteps, double dt, MP6 m, V10 qd, V7 rd, const double *u,
+                                                 int u_per_scenario, const double *meas_noise, double *x, double *ekf_x,
+                                                 double *ekf_P, double *x_hist, double *est_hist)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    const ModelParams mp = to_mp(m);
+    const PlantCoef pc = plant_coef(mp, x[(size_t)s * 10 + 4]);
+    double xs[10], y[7];
+#pragma unroll
+    for (int i = 0; i < 10; i++) xs[i] = x[(size_t)s * 10 + i];
+    double *xe = ekf_x + (size_t)s * 10, *Pe = ekf_P + (size_t)s * 100;
+    for (int t = 0; t < nsteps; t++) {
+        const double ut = u_per_scenario ? u[(size_t)t * B + s] : u[t];
+        plant_rk4_c<10>(xs, ut, dt, pc);
+        ekf_time_update_one(dt, mp, qd, xe, Pe, ut);
+#pragma unroll
+        for (int a = 0; a < 7; a++) {
+            const int idx = a < 5 ? a : a + 1;                       // measured entries 0, 1, 2, 3, 4, 6, 7
+            y[a] = xs[idx] + (meas_noise ? meas_noise[((size_t)t * B + s) * 7 + a] : 0.0);
+        }
+        ekf_meas_update_one(rd, xe, Pe, y, nullptr, 0);
+        if (x_hist)
+#pragma unroll
+            for (int i = 0; i < 10; i++) x_hist[((size_t)t * B + s) * 10 + i] = xs[i];
+        if (est_hist)
+            for (int i = 0; i < 10; i++) est_hist[((size_t)t * B + s) * 10 + i] = xe[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) x[(size_t)s * 10 + i] = xs[i];
+}
+
+hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const double *mp6, const double *qd,
+                           const double *rd, const double *u, int u_per_scenario, const double *meas_noise, double *x,
+                           double *ekf_x, double *ekf_P, double *x_hist, double *est_hist)
+{
+    hipLaunchKernelGGL(k_lsim_run, dim3((B + 63) / 64), dim3(64), 0, st, B, nsteps, dt, mp6_from_host(mp6),
+                       v10_from_host(qd), v7_from_host(rd), u, u_per_scenario, meas_noise, x, ekf_x, ekf_P, x_hist, est_hist);
     return hipGetLastError();
 }
 

@@ -87,6 +87,12 @@ hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const do
                                double *prev_progress, const double *target_vel, double *wp_out, double *progress_out);
 hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
                             double *wp_out, double *progress_out, double *abs_out);
+hipError_t launch_dlqr_run(hipStream_t st, int B, int nx, int nsteps, double dt, const double *mp6, const double *K5,
+                           const double *K_scen, double rate_limit, double angle_limit, double *x, double *u_hist,
+                           double *x_hist);
+hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const double *mp6, const double *qd,
+                           const double *rd, const double *u, int u_per_scenario, const double *meas_noise, double *x,
+                           double *ekf_x, double *ekf_P, double *x_hist, double *est_hist);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
                         double *out16);
 

@@ -263,6 +263,76 @@ def test_step_simulator_simulate_lsim_dlqr(orc64, golden):
         np.testing.assert_allclose(xs3[i], x, rtol=1e-12, atol=1e-12)
 
 
+def test_batched_lqr_baseline_and_lsim(orc64, golden):
+    """StepLQRBatch / LsimBatch: every scenario of one launch follows the per-scenario loops of StepSimulator.dlqr_sim
+    and StepSimulator.lsim (checked against the CPU plant / EKF and the reference-recorded EKF trace)."""
+    from oracle import oracle as O
+    from mpc_amd.batched import LsimBatch, StepLQRBatch
+    from mpc_amd.controllers import LOcp
+    N, Tf, n = 50, 0.5, 60
+    dt = Tf / N
+    cfg = O.make_cfg("L", N, Tf)
+    K0 = np.asarray(LOcp(N, Tf, _host_only=True).K, dtype=np.float64).reshape(5)
+    rng = np.random.default_rng(11)
+    B = 37
+    starts = np.tile(np.array([-1.0, 0.0, 1.0, 0.0, 8.0, 0.0, 0.0, 0.0]), (B, 1))
+    starts[:, 1] = rng.uniform(-1.5, 1.5, B); starts[:, 7] = rng.uniform(-0.25, 0.25, B)
+    gains = K0[None, :] * rng.uniform(0.3, 3.0, (B, 1))
+    gains[0] = K0
+    lqr = StepLQRBatch(dt, starts, gains)
+    xs, us = lqr.run(n)
+    xs = xs.cpu().numpy(); us = us.cpu().numpy()
+    saturated = 0
+    for b in range(B):
+        x = starts[b].copy()
+        for i in range(n):
+            u = gains[b] @ (np.array([1 / 500, 0, 0, 0, 0]) - x[[1, 3, 5, 6, 7]])
+            u0 = u
+            u = np.clip(u, -0.9, 0.9); u = np.clip(u, (-0.3 - x[7]) / dt, (0.3 - x[7]) / dt)
+            saturated += int(u != u0)
+            assert abs(us[i, b] - u) <= 1e-9 * max(1.0, abs(u)), (b, i)
+            x = orc64.plant_rk4(x, float(us[i, b]), dt, cfg[3:9])
+            np.testing.assert_allclose(xs[i, b], x, rtol=1e-12, atol=1e-12)
+    assert saturated > 50                                     # the clips are exercised
+    np.testing.assert_array_equal(lqr.state.cpu().numpy(), xs[-1])
+    # one shared gain == the same gain per scenario, bit for bit
+    a = StepLQRBatch(dt, starts[:5], K0).run(20)[0].cpu().numpy()
+    b_ = StepLQRBatch(dt, starts[:5], np.tile(K0, (5, 1))).run(20)[0].cpu().numpy()
+    np.testing.assert_array_equal(a, b_)
+
+    # lsim: scenario 0 replays the reference-recorded trace; the others carry their own input sequence
+    g = golden["ekf"]
+    nn = 40
+    dt2 = float(g["ekf_dt"])
+    Bl = 9
+    true0 = np.tile(np.asarray(g["ekf_true0"], dtype=np.float64), (Bl, 1))
+    est0 = np.tile(np.asarray(g["ekf_x0"], dtype=np.float64), (Bl, 1))
+    true0[1:, 1] += rng.uniform(-0.5, 0.5, Bl - 1); est0[1:, 5] += rng.uniform(-0.2, 0.2, Bl - 1)
+    u = np.tile(np.asarray(g["ekf_u"], dtype=np.float64)[:nn, None], (1, Bl))
+    u[:, 1:] += rng.uniform(-0.2, 0.2, (nn, Bl - 1))
+    sim = LsimBatch(dt2, true0, est0)
+    st, est = sim.run(u)
+    st = st.cpu().numpy(); est = est.cpu().numpy()
+    np.testing.assert_allclose(st[:, 0], g["ekf_true"][:nn], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(est[:, 0], g["ekf_x"][:nn], rtol=1e-8, atol=1e-9)
+    from mpc_amd.EKF import P0_DIAG, Q_DIAG
+    mp = cfg[3:9]
+    Rd = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])
+    for b in range(Bl):
+        x = true0[b].copy(); xe = est0[b].copy(); P = np.diag(np.asarray(P0_DIAG, dtype=np.float64))
+        for i in range(nn):
+            x = orc64.plant_rk4(x, float(u[i, b]), dt2, mp)
+            xe, P = orc64.ekf_time_update(xe, P, float(u[i, b]), dt2, mp, np.asarray(Q_DIAG, dtype=np.float64))
+            xe, P = orc64.ekf_meas_update(xe, P, x[[0, 1, 2, 3, 4, 6, 7]], Rd)[:2]
+            np.testing.assert_allclose(st[i, b], x, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(est[i, b], xe, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sim.P.cpu().numpy()[Bl - 1], P, rtol=1e-7, atol=1e-9)
+    # a shared (n,) sequence == the same sequence handed over per scenario
+    s1 = LsimBatch(dt2, true0, est0).run(u[:, 0].copy())[1].cpu().numpy()
+    s2 = LsimBatch(dt2, true0, est0).run(np.tile(u[:, :1], (1, Bl)))[1].cpu().numpy()
+    np.testing.assert_array_equal(s1, s2)
+
+
 def test_library_error_paths():
     """Argument checks of the C ABI: unsupported horizon, oversize batch, missing buffers raise with a message."""
     from mpc_amd.controllers import LOcp
