@@ -169,13 +169,28 @@ int mpc_lsim_run(void *stream, int B, int nsteps, double dt, const double *mp6_h
                  const double *r_diag_host, const double *u, int u_per_scenario, const double *meas_noise, double *state10,
                  double *ekf_x, double *ekf_P, double *x_hist, double *est_hist);
 
-/* SkidpadPlanner.request_waypoints (utils/path_planning.py:220-261, laps 0..7) and
+/* SkidpadPlanner.request_waypoints (utils/path_planning.py:220-261, constant-speed branch whatever the lap) and
  * StepPlanner.request_waypoints (utils/step_planning.py:88-117): pose [B][3] = x, y, heading;
  * wp_out [B][N+1][4]; progress_out [B]; abs_out [B][N+1][4] (step planner, may be NULL). */
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out);
 int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, const double *target_vel, double *wp_out,
                   double *progress_out, double *abs_out);
+/* SkidpadPlanner.request_waypoints with its speed profile (utils/path_planning.py:220-261 incl. the branch for laps
+ * outside 0..7, :241-248, and progress2speed, :93-126): as mpc_plan_skidpad, plus zones [B][7] = accel_zone_1_start,
+ * accel_zone_1_end, braking_zone_1_start, braking_zone_1_end, braking_zone_2_start, braking_zone_2_end,
+ * slowdown_speed_factor (the planner's attributes, :63-84), and speeds_out [B][N+1] (optional): the target speed on laps
+ * 0..7, the profile (last entry 0) otherwise. */
+int mpc_plan_skidpad_profile(void *stream, int B, int N, double dt, const double *pose, const int *lap,
+                             double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
+                             double *progress_out, double *speeds_out);
+
+/* Control-buffer read-out of the vehicle node (archive/mpc_node.py:421-427): between two solves the steering command is
+ * the predicted steering angle, column `col` of traj [B][N+1][ncol] (6 of the 7-column traj_out above), interpolated
+ * like np.interp at t [B] seconds since the solve over the node times linspace(0, Tf, N+1) (clamped outside), times
+ * `scale` (pi / 2 / 0.4 there): steer_out [B]. */
+int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const double *traj, int ncol, int col,
+                              const double *t, double scale, double *steer_out);
 
 /* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
  * copied to a host array of 16 doubles after synchronising the stream:

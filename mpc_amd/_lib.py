@@ -47,7 +47,9 @@ _SIGS = {
     "mpc_dlqr_run": ([_vp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _vp, C.c_double, C.c_double, _vp, _vp, _vp], C.c_int),
     "mpc_lsim_run": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_plan_skidpad": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_plan_skidpad_profile": ([_vp, C.c_int, C.c_int, C.c_double] + [_vp] * 8, C.c_int),
     "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_control_buffer_interp": ([_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_double, _vp], C.c_int),
     "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)

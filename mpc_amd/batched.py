@@ -228,3 +228,19 @@ class LsimBatch:
             _dev.ptr(xs), _dev.ptr(es))
         _lib.check(rc, None, "mpc_lsim_run")
         return xs, es
+
+
+def control_buffer_interp(traj: torch.Tensor, Tf: float, t, col: int = 6, scale: float = np.pi / 2 / 0.4) -> torch.Tensor:
+    """Steering command between two solves (archive/mpc_node.py:421-427): np.interp of the predicted steering angle
+    (column `col` of traj (B, N+1, ncol), e.g. the trajectory solve_batched returns) at t (B,) seconds since the solve
+    over linspace(0, Tf, N+1), times `scale`."""
+    if traj.ndim != 3 or not traj.is_cuda or traj.dtype != torch.float64:
+        raise ValueError("traj must be a (B, N+1, ncol) float64 device tensor")
+    traj = traj.contiguous()
+    B, n1, ncol = traj.shape
+    t = _dev.f64(np.broadcast_to(np.asarray(t, dtype=np.float64), (B,)).copy(), traj.device) if not torch.is_tensor(t) else t.contiguous()
+    out = torch.empty(B, dtype=torch.float64, device=traj.device)
+    rc = _lib.load().mpc_control_buffer_interp(_dev.stream_ptr(traj.device), B, n1 - 1, float(Tf), _dev.ptr(traj), ncol, int(col),
+                                              _dev.ptr(t), float(scale), _dev.ptr(out))
+    _lib.check(rc, None, "mpc_control_buffer_interp")
+    return out

@@ -337,11 +337,32 @@ int mpc_lsim_run(void *stream, int B, int nsteps, double dt, const double *mp6_h
     return MPC_OK;
 }
 
+int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const double *traj, int ncol, int col,
+                              const double *t, double scale, double *steer_out)
+{
+    if (B < 1 || N < 1 || !(Tf > 0.0) || !traj || ncol < 1 || col < 0 || col >= ncol || !t || !steer_out)
+        return fail(nullptr, MPC_EINVAL, "mpc_control_buffer_interp: bad argument");
+    AUX_TRY(mpc::launch_control_interp((hipStream_t)stream, B, N, Tf, traj, ncol, col, t, scale, steer_out));
+    return MPC_OK;
+}
+
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out)
 {
     if (B < 1 || N < 1 || !pose || !lap || !prev_progress || !target_vel || !wp_out) return fail(nullptr, MPC_EINVAL, "mpc_plan_skidpad: bad argument");
-    AUX_TRY(mpc::launch_plan_skidpad((hipStream_t)stream, B, N, dt, pose, lap, prev_progress, target_vel, wp_out, progress_out));
+    AUX_TRY(mpc::launch_plan_skidpad((hipStream_t)stream, B, N, dt, pose, lap, prev_progress, target_vel, nullptr, wp_out,
+                                     progress_out, nullptr));
+    return MPC_OK;
+}
+
+int mpc_plan_skidpad_profile(void *stream, int B, int N, double dt, const double *pose, const int *lap,
+                             double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
+                             double *progress_out, double *speeds_out)
+{
+    if (B < 1 || N < 1 || !pose || !lap || !prev_progress || !target_vel || !zones || !wp_out)
+        return fail(nullptr, MPC_EINVAL, "mpc_plan_skidpad_profile: bad argument");
+    AUX_TRY(mpc::launch_plan_skidpad((hipStream_t)stream, B, N, dt, pose, lap, prev_progress, target_vel, zones, wp_out,
+                                     progress_out, speeds_out));
     return MPC_OK;
 }
 

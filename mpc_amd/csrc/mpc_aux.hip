@@ -298,25 +298,47 @@ hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const d
 }
 
 // ------------------------------------------------------------------------------------------ planners
-// One wavefront per scenario, lane k -> waypoint k (and k + 64, ...).
+// One wavefront per scenario, lane k -> waypoint k (and k + 64, ...).  With `zones` ([B][7]: the six zone edges and the
+// slow-down factor) a skidpad request for a lap outside 0..7 follows the planner's speed profile instead of the
+// constant target speed (utils/path_planning.py:238-248): that recurrence is sequential, so lane 0 walks it and parks
+// the progresses in the x slot of wp_out, from where the lanes turn them into poses.
 __global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const double *pose, const int *lap,
-                                               double *prev_progress, const double *target_vel, double *wp_out,
-                                               double *progress_out, double *abs_out)
+                                               double *prev_progress, const double *target_vel, const double *zones,
+                                               double *wp_out, double *progress_out, double *abs_out, double *speeds_out)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     const double x = pose[3 * (size_t)s], y = pose[3 * (size_t)s + 1], heading = pose[3 * (size_t)s + 2];
     const double v = target_vel[s];
     double p0;
+    bool profile = false;
     if (mode == MODE_SKIDPAD) {
         int lp = lap[s];
         p0 = sk_pos2progress(x, y, lp);
         if (prev_progress[s] > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(x, y, lp); }   // path_planning.py:227-230
+        profile = zones != nullptr && (lp < 0 || lp > 7);
     } else
         p0 = x;
+    double *wps = wp_out + (size_t)s * (N + 1) * 4;
+    if (profile) {
+        if (lane == 0) {
+            const double *zg = zones + 7 * (size_t)s;
+            const SpeedZones z = {zg[0], zg[1], zg[2], zg[3], zg[4], zg[5], zg[6]};
+            double q = p0;
+            for (int i = 0; i < N; i++) {
+                const double sp = sk_stage_speed(z, v, q, dt);
+                wps[4 * i] = q;
+                if (speeds_out) speeds_out[(size_t)s * (N + 1) + i] = sp;
+                q = q + sp * dt;
+            }
+            wps[4 * N] = q;
+            if (speeds_out) speeds_out[(size_t)s * (N + 1) + N] = 0.0;      // the last entry keeps its initial zero
+        }
+        __syncthreads();
+    }
     const double ch = cos(heading), sh = sin(heading);
     for (int k = lane; k <= N; k += WAVE) {
         double o[4];
-        const double q = waypoint_progress(p0, v, dt, k);
+        const double q = profile ? wps[4 * k] : waypoint_progress(p0, v, dt, k);
         if (mode == MODE_SKIDPAD) sk_pose(q, o);
         else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
         if (abs_out) {
@@ -324,8 +346,9 @@ __global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const
             w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
         }
         to_car_frame(o, x, y, ch, sh);
-        double *w = wp_out + ((size_t)s * (N + 1) + k) * 4;
+        double *w = wps + (size_t)k * 4;
         w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+        if (speeds_out && !profile) speeds_out[(size_t)s * (N + 1) + k] = v;
     }
     __syncthreads();
     if (lane == 0) {
@@ -335,10 +358,11 @@ __global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const
 }
 
 hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const double *pose, const int *lap,
-                               double *prev_progress, const double *target_vel, double *wp_out, double *progress_out)
+                               double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
+                               double *progress_out, double *speeds_out)
 {
     hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_SKIDPAD, N, dt, pose, lap, prev_progress,
-                       target_vel, wp_out, progress_out, (double *)nullptr);
+                       target_vel, zones, wp_out, progress_out, (double *)nullptr, speeds_out);
     return hipGetLastError();
 }
 
@@ -346,7 +370,44 @@ hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const doubl
                             double *wp_out, double *progress_out, double *abs_out)
 {
     hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_STEP, N, dt, pose, (const int *)nullptr,
-                       (double *)nullptr, target_vel, wp_out, progress_out, abs_out);
+                       (double *)nullptr, target_vel, (const double *)nullptr, wp_out, progress_out, abs_out,
+                       (double *)nullptr);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------- control buffer
+// archive/mpc_node.py:421-427: between two solves the vehicle node steers with the predicted steering-angle trajectory
+// (column `col` of the solver's state trajectory) interpolated at the time since the solve, np.interp over the node
+// times linspace(0, Tf, N + 1), times `scale` (pi / 2 / 0.4 there).  np.interp clamps outside the table and evaluates
+// slope * (t - t_j) + f_j inside it.
+__global__ __launch_bounds__(256) void k_control_interp(int B, int N, double Tf, const double *traj, int ncol, int col,
+                                                        const double *t, double scale, double *out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    const double *f = traj + (size_t)s * (N + 1) * ncol + col;
+    const double step = Tf / N, x = t[s];
+    double r;
+    if (x != x) r = x;
+    else if (x <= 0.0) r = f[0];                         // left of (or on) the first node
+    else if (x >= Tf) r = f[(size_t)N * ncol];
+    else {
+        int j = (int)(x / step);
+        if (j > N - 1) j = N - 1;
+        auto node = [&](int i) { return i == N ? Tf : i * step; };      // linspace: i * step, the end point exact
+        while (j > 0 && node(j) > x) j--;
+        while (j < N - 1 && node(j + 1) <= x) j++;
+        const double f0 = f[(size_t)j * ncol], f1 = f[(size_t)(j + 1) * ncol];
+        const double slope = (f1 - f0) / (node(j + 1) - node(j));
+        r = slope * (x - node(j)) + f0;
+    }
+    out[s] = r * scale;
+}
+
+hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const double *traj, int ncol, int col,
+                                 const double *t, double scale, double *out)
+{
+    hipLaunchKernelGGL(k_control_interp, dim3((B + 255) / 256), dim3(256), 0, st, B, N, Tf, traj, ncol, col, t, scale, out);
     return hipGetLastError();
 }
 

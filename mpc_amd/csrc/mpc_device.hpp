@@ -239,4 +239,28 @@ __device__ __forceinline__ double waypoint_progress(double p0, double v, double 
     return p0 + speed_cumsum(v, k) * dt;
 }
 
+// Speed zones of the skidpad planner (utils/path_planning.py:63-84): acceleration zone, first braking zone (to the
+// slow-down speed), second braking zone (to standstill); f is the slow-down speed factor.
+struct SpeedZones { double a1s, a1e, b1s, b1e, b2s, b2e, f; };
+
+// utils/path_planning.py:93-126; a progress exactly on a zone edge falls through to the 0.1 of the last branch.
+__device__ __forceinline__ double sk_progress2speed(const SpeedZones &z, double v, double q)
+{
+    if (q > z.b2e) return 0.0;
+    if (z.b2e > q && q > z.b2s) return v * z.f - (q - z.b2s) * v * z.f;
+    if (z.b2s > q && q > z.b1e) return v * z.f;
+    if (z.b1e > q && q > z.b1s) return v - (q - z.b1s) * v * (1.0 - z.f);
+    if (z.b1s > q && q > z.a1e) return v;
+    if (z.a1e > q && q > z.a1s) return (q - z.a1s) * (v - 0.1) + 0.1;
+    return 0.1;
+}
+
+// One stage of the speed profile (utils/path_planning.py:242-248): the speed the planner keeps is the one at the
+// midpoint of a step taken with the speed at the stage's progress, both capped at the target speed.
+__device__ __forceinline__ double sk_stage_speed(const SpeedZones &z, double v, double q, double dt)
+{
+    const double s0 = fmin(sk_progress2speed(z, v, q), v);
+    return fmin(sk_progress2speed(z, v, q + s0 * dt / 2), v);
+}
+
 }  // namespace mpc

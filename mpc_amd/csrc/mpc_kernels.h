@@ -84,7 +84,8 @@ hipError_t launch_ekf_meas_update(hipStream_t st, int B, const double *rd, doubl
                                   double *K_out, int gain_only);
 hipError_t launch_ekf_jacobian(hipStream_t st, int B, double dt, const double *mp6, const double *x, double *F);
 hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const double *pose, const int *lap,
-                               double *prev_progress, const double *target_vel, double *wp_out, double *progress_out);
+                               double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
+                               double *progress_out, double *speeds_out);
 hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
                             double *wp_out, double *progress_out, double *abs_out);
 hipError_t launch_dlqr_run(hipStream_t st, int B, int nx, int nsteps, double dt, const double *mp6, const double *K5,
@@ -93,6 +94,8 @@ hipError_t launch_dlqr_run(hipStream_t st, int B, int nx, int nsteps, double dt,
 hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const double *mp6, const double *qd,
                            const double *rd, const double *u, int u_per_scenario, const double *meas_noise, double *x,
                            double *ekf_x, double *ekf_P, double *x_hist, double *est_hist);
+hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const double *traj, int ncol, int col,
+                                 const double *t, double scale, double *out);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
                         double *out16);
 

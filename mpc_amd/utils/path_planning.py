@@ -62,35 +62,70 @@ class SkidpadPlanner:
             lap_correct = False
         return current_progress, lap_correct
 
-    def request_waypoints_batched(self, pose, lap, prev_progress, target_vel, Nt=None, dt=None):
-        """pose (B,3) = x, y, heading; lap (B,) int32; prev_progress (B,) is updated in place (device tensors)."""
+    def zones(self) -> np.ndarray:
+        """The seven numbers the speed profile depends on, in the order the kernel reads them."""
+        return np.array([self.accel_zone_1_start, self.accel_zone_1_end, self.braking_zone_1_start,
+                         self.braking_zone_1_end, self.braking_zone_2_start, self.braking_zone_2_end,
+                         self.slowdown_speed_factor], dtype=np.float64)
+
+    def progress2speed(self, progress):
+        """Scalar helper (utils/path_planning.py:93-126); the kernel carries its own copy."""
+        v, f = self.target_vel, self.slowdown_speed_factor
+        if progress > self.braking_zone_2_end:
+            return 0
+        if self.braking_zone_2_end > progress > self.braking_zone_2_start:
+            return v * f - (progress - self.braking_zone_2_start) * v * f
+        if self.braking_zone_2_start > progress > self.braking_zone_1_end:
+            return v * f
+        if self.braking_zone_1_end > progress > self.braking_zone_1_start:
+            return v - (progress - self.braking_zone_1_start) * v * (1 - f)
+        if self.braking_zone_1_start > progress > self.accel_zone_1_end:
+            return v
+        if self.accel_zone_1_end > progress > self.accel_zone_1_start:
+            return (progress - self.accel_zone_1_start) * (v - 0.1) + 0.1
+        return 0.1
+
+    def request_waypoints_batched(self, pose, lap, prev_progress, target_vel, Nt=None, dt=None, zones=None,
+                                  return_speeds=False):
+        """pose (B,3) = x, y, heading; lap (B,) int32; prev_progress (B,) is updated in place (device tensors).
+        zones (B,7) (see zones()) switches the speed profile on for laps outside 0..7; without it every lap is planned
+        at the constant target speed."""
         dev = self.device
         Nt = self.Nt if Nt is None else Nt
         dt = self.dt if dt is None else dt
         pose = _dev.f64(pose, dev); B = pose.shape[0]
         wp = torch.empty((B, Nt + 1, 4), dtype=torch.float64, device=dev)
         prog = torch.empty((B,), dtype=torch.float64, device=dev)
-        rc = self._lib.mpc_plan_skidpad(_dev.stream_ptr(dev), B, int(Nt), float(dt), _dev.ptr(pose), _dev.ptr(lap),
-                                        _dev.ptr(prev_progress), _dev.ptr(target_vel), _dev.ptr(wp), _dev.ptr(prog))
-        _lib.check(rc, None, "mpc_plan_skidpad")
-        return wp, prog
+        if zones is None and not return_speeds:
+            rc = self._lib.mpc_plan_skidpad(_dev.stream_ptr(dev), B, int(Nt), float(dt), _dev.ptr(pose), _dev.ptr(lap),
+                                            _dev.ptr(prev_progress), _dev.ptr(target_vel), _dev.ptr(wp), _dev.ptr(prog))
+            _lib.check(rc, None, "mpc_plan_skidpad")
+            return wp, prog
+        if zones is None:
+            zones = np.tile(self.zones(), (B, 1))
+        zones = _dev.f64(zones, dev)
+        if tuple(zones.shape) != (B, 7):
+            raise ValueError("zones must be (B, 7)")
+        speeds = torch.empty((B, Nt + 1), dtype=torch.float64, device=dev)
+        rc = self._lib.mpc_plan_skidpad_profile(_dev.stream_ptr(dev), B, int(Nt), float(dt), _dev.ptr(pose), _dev.ptr(lap),
+                                                _dev.ptr(prev_progress), _dev.ptr(target_vel), _dev.ptr(zones), _dev.ptr(wp),
+                                                _dev.ptr(prog), _dev.ptr(speeds))
+        _lib.check(rc, None, "mpc_plan_skidpad_profile")
+        return (wp, prog, speeds) if return_speeds else (wp, prog)
 
     def request_waypoints(self, x, y, heading, lap, Nt=-1, dt=-1):
         if Nt == -1:
             Nt = self.Nt
         if dt == -1:
             dt = self.dt
-        if lap not in range(0, 8):
-            raise NotImplementedError("the acceleration/braking speed profile (laps outside 0..7) is not implemented")
         dev = self.device
         pp = _dev.f64(np.array([float(self.prev_progress)]), dev).clone()
-        wp, prog = self.request_waypoints_batched(np.array([[x, y, heading]], dtype=np.float64),
-                                                  _dev.i32(np.array([lap]), dev), pp,
-                                                  _dev.f64(np.array([float(self.target_vel)]), dev), Nt, dt)
+        wp, prog, speeds = self.request_waypoints_batched(
+            np.array([[x, y, heading]], dtype=np.float64), _dev.i32(np.array([lap]), dev), pp,
+            _dev.f64(np.array([float(self.target_vel)]), dev), Nt, dt, zones=self.zones()[None], return_speeds=True)
         self.prev_progress = float(pp.item())
-        speeds = self.target_vel * np.ones((Nt + 1))
         heading_derotation = np.array([[np.cos(heading), -np.sin(heading)], [np.sin(heading), np.cos(heading)]])
-        return wp.cpu().numpy()[0], speeds, float(prog.item()), heading_derotation
+        return wp.cpu().numpy()[0], speeds.cpu().numpy()[0], float(prog.item()), heading_derotation
 
     def request_desired_speed(self, progress) -> float:
         if progress < self.braking_zone_1_start:

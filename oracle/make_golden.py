@@ -148,6 +148,38 @@ def main():
                st_dt=np.array(dt), st_v=np.array(v))
     np.savez_compressed(os.path.join(OUT, "planners.npz"), **rec)
 
+    # ---- planner speed profile (laps outside 0..7), progress2speed, request_desired_speed ----
+    rec = {}
+    prng = np.random.default_rng(77)
+    cases = []
+    for (v, acc, fac, start) in ((9.0, 10.0, 0.5, None), (8.0, 10.0, 0.5, 3.0), (12.0, 6.0, 0.3, None), (5.0, 10.0, 0.7, None)):
+        pl = SkidpadPlanner(target_vel=v, max_accel=acc, Nt=40, dt=(0.05 if fac == 0.5 else 0.1), slowdown_speed_factor=fac)
+        if start is not None:
+            pl.set_starting_position(start)
+        zones = np.array([pl.accel_zone_1_start, pl.accel_zone_1_end, pl.braking_zone_1_start, pl.braking_zone_1_end,
+                          pl.braking_zone_2_start, pl.braking_zone_2_end, pl.slowdown_speed_factor], dtype=np.float64)
+        qs = np.concatenate([np.linspace(-2.0, 30.0, 60), np.linspace(4 * 2 * 9.125 * np.pi + 10, 4 * 2 * 9.125 * np.pi + 45, 120),
+                             zones[:6]])
+        sp = np.array([pl.progress2speed(q) for q in qs], dtype=np.float64)
+        ds = np.array([pl.request_desired_speed(q) for q in qs], dtype=np.float64)
+        reqs = []
+        for lap in (8, 9, -1, 8, 8, 8, 8, 8):
+            px = prng.uniform(-1.0, 48.0); py = prng.uniform(-0.4, 0.4); hd = prng.uniform(-0.2, 0.2)
+            N = int(prng.choice([10, 40, 80])); dtt = pl.dt     # an explicit dt leaves prev_progress unbound there (:223-228)
+            prev = pl.prev_progress
+            w, spd, p0, R = pl.request_waypoints(px, py, hd, lap, Nt=N)
+            reqs.append(dict(pose=np.array([px, py, hd]), lap=lap, N=N, dt=dtt, prev=prev, wp=w.copy(), speeds=spd.copy(),
+                             p0=p0, prev_after=pl.prev_progress))
+        cases.append(dict(v=v, zones=zones, qs=qs, sp=sp, ds=ds, reqs=reqs))
+    for ci, c in enumerate(cases):
+        rec[f"c{ci}_v"] = np.array(c["v"]); rec[f"c{ci}_zones"] = c["zones"]; rec[f"c{ci}_qs"] = c["qs"]
+        rec[f"c{ci}_sp"] = c["sp"]; rec[f"c{ci}_ds"] = c["ds"]; rec[f"c{ci}_nreq"] = np.array(len(c["reqs"]))
+        for ri, q in enumerate(c["reqs"]):
+            for k, val in q.items():
+                rec[f"c{ci}_r{ri}_{k}"] = np.asarray(val)
+    rec["ncases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "planner_speed_profile.npz"), **rec)
+
     # ---- known answers held by the reference: terminal_set.m:4-10 (A 5x5, B at vx=15, dt=0.02), values as printed ----
     A = np.array([[1.0, 0.3, 0.02, 0.0, 0.0],
                   [0.0, 1.0, 0.0, 0.02, 0.0],

@@ -29,8 +29,7 @@ _ip = C.POINTER(C.c_int)
 
 def build(force: bool = False) -> None:
     """Compile both precisions of the checker with gcc (a few seconds)."""
-    if force or not all(os.path.exists(os.path.join(_BUILD, f"liboracle_{p}.so")) for p in ("f64", "f80")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))      # make rebuilds only what is stale
 
 
 def _ptr(a):
@@ -54,6 +53,11 @@ class Oracle:
         L.orc_ekf_meas_update.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_skidpad_waypoints.argtypes = [C.c_double] * 3 + [C.c_int, _dp, C.c_double, C.c_int, C.c_double, _dp, _dp]
         L.orc_skidpad_waypoints.restype = C.c_double
+        L.orc_skidpad_waypoints_profile.argtypes = ([C.c_double] * 3 + [C.c_int, _dp, C.c_double, C.c_int, C.c_double, _dp, _dp,
+                                                                        _dp])
+        L.orc_skidpad_waypoints_profile.restype = C.c_double
+        L.orc_progress2speed.argtypes = [_dp, C.c_double, C.c_double]
+        L.orc_progress2speed.restype = C.c_double
         L.orc_step_waypoints.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, _dp, _dp, _dp]
         L.orc_step_waypoints.restype = C.c_double
         L.orc_mpc_optimize.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
@@ -115,6 +119,17 @@ class Oracle:
                                             float(dt), _ptr(wp), _ptr(sp))
         return wp, sp, p0, float(pp[0])
 
+    def skidpad_waypoints_profile(self, x, y, heading, lap, prev_progress, v, N, dt, zones):
+        """request_waypoints with the speed profile for laps outside 0..7; zones = planner_zones(...)."""
+        wp = np.zeros((N + 1, 4)); sp = np.zeros(N + 1); pp = np.array([prev_progress], dtype=np.float64)
+        z = np.ascontiguousarray(zones, dtype=np.float64)
+        p0 = self.lib.orc_skidpad_waypoints_profile(float(x), float(y), float(heading), int(lap), _ptr(pp), float(v),
+                                                    int(N), float(dt), _ptr(z), _ptr(wp), _ptr(sp))
+        return wp, sp, p0, float(pp[0])
+
+    def progress2speed(self, zones, v, q):
+        return self.lib.orc_progress2speed(_ptr(np.ascontiguousarray(zones, dtype=np.float64)), float(v), float(q))
+
     def step_waypoints(self, x, y, heading, v, N, dt):
         wp = np.zeros((N + 1, 4)); sp = np.zeros(N + 1); ab = np.zeros((N + 1, 4))
         p0 = self.lib.orc_step_waypoints(float(x), float(y), float(heading), float(v), int(N), float(dt), _ptr(wp),
@@ -168,6 +183,23 @@ class Oracle:
 # controller configuration (host-side restatement of the reference constructors)
 # ---------------------------------------------------------------------------
 _DEFAULT_CFG_DIR = os.path.join(os.path.dirname(_HERE), "mpc_amd", "config")
+
+
+def planner_zones(target_vel, max_accel=10.0, slowdown_speed_factor=0.5, start_progress=None):
+    """The planner's zone edges (utils/path_planning.py:63-91): accel 1 start/end, braking 1 start/end, braking 2
+    start/end, and the slow-down factor; start_progress = the argument of set_starting_position, if it was called."""
+    r, center, end_straight = 9.125, 16.75, 15
+    lap_length = 2 * r * np.pi
+    accel_time = target_vel / max_accel
+    a1s = 0 if start_progress is None else start_progress
+    a1e = max_accel / 2 * accel_time * accel_time + (0 if start_progress is None else start_progress)
+    decel_time = accel_time * (1 - slowdown_speed_factor)
+    b1s = center + 1 + 4 * lap_length
+    b1e = b1s + decel_time * target_vel + max_accel / 2 * decel_time * decel_time
+    decel_time_2 = accel_time * slowdown_speed_factor
+    b2s = center + end_straight + 4 * lap_length
+    b2e = b2s + decel_time_2 * max_accel
+    return np.array([a1s, a1e, b1s, b1e, b2s, b2e, slowdown_speed_factor], dtype=np.float64)
 
 
 def load_params(kind: str, path: str | None = None) -> dict:

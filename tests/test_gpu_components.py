@@ -89,6 +89,51 @@ def test_planners_match_reference_vectors(golden):
         assert p0 == pose[0] and np.all(speeds == v)
 
 
+def test_skidpad_planner_speed_profile(orc64, golden):
+    """Laps outside 0..7: the speed profile of utils/path_planning.py:241-248 through the class surface and batched,
+    against the reference's recorded outputs and the CPU restatement."""
+    import torch
+    from mpc_amd.utils.path_planning import SkidpadPlanner
+    g = golden["planner_speed_profile"]
+    params = ((9.0, 10.0, 0.5, None), (8.0, 10.0, 0.5, 3.0), (12.0, 6.0, 0.3, None), (5.0, 10.0, 0.7, None))
+    for ci, (v, acc, fac, start) in enumerate(params):
+        dt = 0.05 if fac == 0.5 else 0.1
+        pl = SkidpadPlanner(target_vel=v, max_accel=acc, Nt=40, dt=dt, slowdown_speed_factor=fac)
+        if start is not None:
+            pl.set_starting_position(start)
+        np.testing.assert_array_equal(pl.zones(), g[f"c{ci}_zones"])
+        np.testing.assert_allclose([pl.progress2speed(q) for q in g[f"c{ci}_qs"]], g[f"c{ci}_sp"], rtol=1e-15, atol=1e-15)
+        np.testing.assert_array_equal([pl.request_desired_speed(q) for q in g[f"c{ci}_qs"]], g[f"c{ci}_ds"])
+        nreq = int(g[f"c{ci}_nreq"])
+        for ri in range(nreq):
+            q = {k: g[f"c{ci}_r{ri}_{k}"] for k in ("pose", "lap", "N", "prev", "wp", "speeds", "p0", "prev_after")}
+            assert pl.prev_progress == pytest.approx(float(q["prev"]), rel=1e-14, abs=1e-13)
+            w, spd, p0, R = pl.request_waypoints(*q["pose"], int(q["lap"]), Nt=int(q["N"]))
+            np.testing.assert_allclose(spd, q["speeds"], rtol=1e-14, atol=1e-14)
+            np.testing.assert_allclose(w, q["wp"], rtol=1e-11, atol=1e-11)
+            assert p0 == pytest.approx(float(q["p0"]), rel=1e-14, abs=1e-13)
+    # batched: mixed laps (constant-speed and profile scenarios in one launch), per-scenario zones and speeds
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    B, N, dt = 64, 70, 0.04
+    pl = SkidpadPlanner(target_vel=9.0, Nt=N, dt=dt)
+    dev = pl.device
+    lap = rng.choice([0, 5, 7, 8, 9, -1], B).astype(np.int32)
+    pose = np.stack([rng.uniform(-1, 50, B), rng.uniform(-0.4, 0.4, B), rng.uniform(-0.2, 0.2, B)], axis=1)
+    tv = rng.uniform(5.0, 12.0, B)
+    zones = np.stack([O.planner_zones(tv[b], rng.uniform(6, 12), rng.uniform(0.3, 0.7)) for b in range(B)])
+    prev0 = rng.uniform(0.0, 5.0, B)
+    prev = torch.as_tensor(prev0, device=dev).clone()
+    wps, prog, speeds = pl.request_waypoints_batched(torch.as_tensor(pose, device=dev), torch.as_tensor(lap, device=dev), prev,
+                                                     torch.as_tensor(tv, device=dev), zones=zones, return_speeds=True)
+    wps = wps.cpu().numpy(); speeds = speeds.cpu().numpy(); prog = prog.cpu().numpy(); prev = prev.cpu().numpy()
+    for b in range(B):
+        wr, sr, p0, pa = orc64.skidpad_waypoints_profile(*pose[b], int(lap[b]), prev0[b], tv[b], N, dt, zones[b])
+        np.testing.assert_allclose(speeds[b], sr, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(wps[b], wr, rtol=1e-10, atol=1e-10)
+        assert prog[b] == pytest.approx(p0, rel=1e-14, abs=1e-13) and prev[b] == pytest.approx(pa, rel=1e-14, abs=1e-13)
+
+
 def _utol(u_ref, umax=0.9):
     return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
 
@@ -331,6 +376,25 @@ def test_batched_lqr_baseline_and_lsim(orc64, golden):
     s1 = LsimBatch(dt2, true0, est0).run(u[:, 0].copy())[1].cpu().numpy()
     s2 = LsimBatch(dt2, true0, est0).run(np.tile(u[:, :1], (1, Bl)))[1].cpu().numpy()
     np.testing.assert_array_equal(s1, s2)
+
+
+def test_control_buffer_interp_matches_numpy():
+    """archive/mpc_node.py:421-427 is np.interp over linspace(0, Tf, N+1); numpy is the reference's own arithmetic here."""
+    import torch
+    from mpc_amd.batched import control_buffer_interp
+    rng = np.random.default_rng(5)
+    for N, Tf in ((50, 0.5), (80, 2.0), (7, 0.35), (128, 1.28)):
+        B = 300
+        traj = rng.normal(size=(B, N + 1, 7))
+        nodes = np.linspace(0, Tf, N + 1)
+        t = rng.uniform(-0.1 * Tf, 1.1 * Tf, B)
+        t[:N + 1] = nodes[:min(B, N + 1)]                       # exactly on the nodes
+        t[N + 1:2 * N + 1] = np.nextafter(nodes[:N], 1.0)[:B - N - 1]
+        want = np.array([np.interp(t[b], nodes, traj[b, :, 6]) for b in range(B)]) * np.pi / 2 / 0.4
+        got = control_buffer_interp(torch.as_tensor(traj, device="cuda"), Tf, t).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-14)
+        got0 = control_buffer_interp(torch.as_tensor(traj, device="cuda"), Tf, 0.013, col=2, scale=1.0).cpu().numpy()
+        np.testing.assert_allclose(got0, [np.interp(0.013, nodes, traj[b, :, 2]) for b in range(B)], rtol=1e-13, atol=1e-14)
 
 
 def test_library_error_paths():

@@ -87,6 +87,39 @@ def test_skidpad_planner_full_track(orc64, golden):
     assert laps_seen >= {0, 1, 2, 3, 4, 5}          # all four track regions exercised
 
 
+def _profile_cases(g):
+    for ci in range(int(g["ncases"])):
+        reqs = []
+        for ri in range(int(g[f"c{ci}_nreq"])):
+            reqs.append({k: g[f"c{ci}_r{ri}_{k}"] for k in ("pose", "lap", "N", "dt", "prev", "wp", "speeds", "p0", "prev_after")})
+        yield float(g[f"c{ci}_v"]), g[f"c{ci}_zones"], g[f"c{ci}_qs"], g[f"c{ci}_sp"], g[f"c{ci}_ds"], reqs
+
+
+def test_skidpad_planner_speed_profile(orc64, golden):
+    """Laps outside 0..7 (utils/path_planning.py:241-248) and progress2speed (:93-126) against the reference's outputs;
+    the zone edges recorded from the reference's planner objects pin planner_zones (:63-91) as well."""
+    g = golden["planner_speed_profile"]
+    params = ((9.0, 10.0, 0.5, None), (8.0, 10.0, 0.5, 3.0), (12.0, 6.0, 0.3, None), (5.0, 10.0, 0.7, None))
+    branches = set()
+    for (v, zones, qs, sp_ref, ds_ref, reqs), (pv, acc, fac, start) in zip(_profile_cases(g), params):
+        assert v == pv
+        np.testing.assert_array_equal(O.planner_zones(pv, acc, fac, start), zones)
+        sp = np.array([orc64.progress2speed(zones, v, q) for q in qs])
+        np.testing.assert_allclose(sp, sp_ref, rtol=1e-15, atol=1e-15)
+        branches |= set(np.round(sp_ref, 6))
+        for q in reqs:
+            wp, spd, p0, pa = orc64.skidpad_waypoints_profile(q["pose"][0], q["pose"][1], q["pose"][2], int(q["lap"]),
+                                                              float(q["prev"]), v, int(q["N"]), float(q["dt"]), zones)
+            # the checker is compiled with fused multiply-adds; the ramps subtract nearby progresses (~250 m), so the
+            # recurrence carries a few 1e-13 of that rounding difference
+            np.testing.assert_allclose(spd, q["speeds"], rtol=2e-12, atol=2e-12)
+            np.testing.assert_allclose(wp, q["wp"], rtol=1e-11, atol=1e-11)
+            assert p0 == pytest.approx(float(q["p0"]), rel=1e-14, abs=1e-13)
+            assert pa == pytest.approx(float(q["prev_after"]), rel=1e-14, abs=1e-13)
+            assert spd[-1] == float(q["speeds"][-1])           # 0 on the profile branch, v when lap + 1 lands in 0..7
+    assert {0.0, 0.1} <= branches and len(branches) > 20       # stop zone, off-track default and the ramps
+
+
 def test_step_planner(orc64, golden):
     g = golden["planners"]
     N, dt, v = int(g["st_N"]), float(g["st_dt"]), float(g["st_v"])
