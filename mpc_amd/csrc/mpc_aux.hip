@@ -411,6 +411,46 @@ hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const 
     return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------------- load balance
+// Counting sort of the scenarios by the work of their last launch, heaviest first: order[rank] = scenario.  One
+// workgroup; keys are work >> shift clamped to 1023.  Scenarios are independent, so the order among equal keys
+// (decided by the LDS atomics) changes no result, only which wave advances which scenario.
+__global__ __launch_bounds__(1024) void k_balance_order(int B, const int *work, int shift, int *order)
+{
+    __shared__ int hist[1024];
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    for (int s = t; s < B; s += 1024) {
+        const int key = min(max(work[s], 0) >> shift, 1023);
+        atomicAdd(&hist[1023 - key], 1);                 // bin 0 = heaviest
+    }
+    __syncthreads();
+    // exclusive prefix over the 1024 bins (Hillis-Steele in LDS)
+    part[t] = hist[t];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    hist[t] = part[t] - hist[t];                         // start offset of bin t
+    __syncthreads();
+    for (int s = t; s < B; s += 1024) {
+        const int key = min(max(work[s], 0) >> shift, 1023);
+        const int pos = atomicAdd(&hist[1023 - key], 1);
+        order[pos] = s;
+    }
+}
+
+hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shift, int *order)
+{
+    hipLaunchKernelGGL(k_balance_order, dim3(1), dim3(1024), 0, st, B, work, shift, order);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ statistics
 // Single-block reduction of the per-scenario solver records into 16 doubles (sums and maxima).
 __global__ __launch_bounds__(256) void k_stats(int B, const double *stat, const int *iters, const int *status,

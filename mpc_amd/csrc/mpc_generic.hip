@@ -169,7 +169,7 @@ __device__ __forceinline__ Vec<R> lds_solve(const double *M, int LD, int N, int 
 template <int R>
 __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveArgs a)
 {
-    const int s = blockIdx.x;
+    const int s = a.order ? a.order[blockIdx.x] : blockIdx.x;      // scenario this wave advances (grid = B workgroups)
     const int lane = threadIdx.x;
     const int N = cfg.N;
     const int LD = N | 1;                 // odd leading dimension: the one strided access per pivot is 2-way at worst
@@ -645,11 +645,12 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     }
     if (lane == 0) {
         if (a.u0_out) a.u0_out[s] = u0;
-        if (a.status_out) a.status_out[s] = status_max;
-        if (a.iters_out) a.iters_out[s] = iters_tot;
+        if (a.work_out) a.work_out[s] = iters_tot;
+        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
+        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
-            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+            so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
     }
 }

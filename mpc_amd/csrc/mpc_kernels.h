@@ -46,6 +46,14 @@ struct SolveArgs {
     int *status_out, *iters_out;
     int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)
     double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
+    // A long closed-loop run is issued as a chain of launches: `order` (a permutation of 0..B-1, or NULL) maps the
+    // wave index to the scenario it advances, so that scenarios that needed many solver iterations in the previous
+    // launch start first and share a workgroup; work_out [B] receives this launch's iterations per scenario; with
+    // `accumulate` the per-scenario totals (iterations, worst status, constrained solves, SQP iterations) add to what
+    // the previous launch of the chain left instead of replacing it.
+    const int *order;
+    int *work_out;
+    int accumulate;
     // Fixed-model cache (every scenario at speed sh_vx with the handle's model parameters); NULL = off.
     const double *sh_H;      // [N][N] condensed Hessian
     const double *sh_Kref;   // [3][N][N]: inv(H) * d g / d ref_c(stage k+1), stored [c][k][i]
@@ -96,6 +104,7 @@ hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const d
                            double *ekf_x, double *ekf_P, double *x_hist, double *est_hist);
 hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const double *traj, int ncol, int col,
                                  const double *t, double scale, double *out);
+hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shift, int *order);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
                         double *out16);
 

@@ -117,7 +117,7 @@ template <int N>
 __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const SolveArgs a)
 {
     const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+    const int s = a.order ? a.order[blockIdx.x] : blockIdx.x;      // scenario this wave advances (grid = B workgroups)
     const bool valid = lane < N, validd = lane < N - 1;
     extern __shared__ double lds[];
     double *s_ref = lds;                              // [4][N+1]: x, y, cos, sin of the car-frame waypoints
@@ -394,12 +394,13 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
     }
     if (lane == 0) {
         if (a.u0_out) a.u0_out[s] = u0;
-        if (a.status_out) a.status_out[s] = status_max;
-        if (a.iters_out) a.iters_out[s] = iters_tot;
-        if (a.sqp_out) a.sqp_out[s] = sqp_tot;
+        if (a.work_out) a.work_out[s] = iters_tot;
+        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
+        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
+        if (a.sqp_out) a.sqp_out[s] = a.accumulate ? a.sqp_out[s] + sqp_tot : sqp_tot;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
-            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+            so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
     }
 }

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps scenario addressing scalar
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * WPB + wave;
+    const int widx = blockIdx.x * WPB + wave;
+    const int s = (a.order && widx < a.B) ? a.order[widx] : widx;       // scenario this wave advances
     const bool valid = lane < N;        // lane owns a decision variable
     const bool validd = lane < N - 1;   // lane owns the bound on delta_{lane+1}
 
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
     if (GENERAL) {
-        if (lane < 36) s_We[lane] = a.cost_scen ? a.cost_scen[43 * (size_t)blockIdx.x + 7 + lane] : cfg.We[lane];
+        if (lane < 36) s_We[lane] = (a.cost_scen && widx < a.B) ? a.cost_scen[43 * (size_t)s + 7 + lane] : cfg.We[lane];
     } else {
         int ci = 0;
 #pragma unroll
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         for (int i = threadIdx.x; i < 5 * N; i += WPB * WAVE) s_Kx[i] = a.sh_Kx[i];
         __syncthreads();                 // the only workgroup-wide barrier: from here on the waves are independent
     }
-    if (s >= a.B) return;
+    if (widx >= a.B) return;
 
     ModelParams mp;
     if (a.mp_scen) {
@@ -435,11 +436,12 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     if (lane == 0) {
         if (warm_rec) warm_rec[5 * WAVE] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
-        if (a.status_out) a.status_out[s] = status_max;
-        if (a.iters_out) a.iters_out[s] = iters_tot;
+        if (a.work_out) a.work_out[s] = iters_tot;
+        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
+        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
-            so[0] = mu; so[1] = res; so[2] = (double)nconstr; so[3] = fabs(u0);
+            so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
     }
 }

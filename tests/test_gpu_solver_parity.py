@@ -108,6 +108,38 @@ def test_fused_run_equals_step_by_step(N, Tf):
     assert torch.equal(a.lap, b.lap) and torch.equal(a.prev_progress, b.prev_progress)
 
 
+@pytest.mark.parametrize("model,N,Tf", [("L", 50, 0.5), ("LPV", 20, 0.4), ("NL", 20, 0.4)])
+def test_chained_rebalanced_run_equals_step_by_step(model, N, Tf):
+    """Runs of a large batch map waves to scenarios in the order of the solver work of the previous launch, and a run
+    longer than 1024 steps goes out as a chain of launches: every scenario's inputs, states, totals and statuses equal the
+    one-launch-per-step run bit for bit."""
+    import torch
+    from mpc_amd.batched import SkidpadBatch
+    rng = np.random.default_rng(8)
+    B, nsteps = 1100, 150                      # >= 1024 scenarios: the second run below is ordered by the work of this one
+    st = _scenarios(rng, B)
+    st[::3, 1] *= 4.0                          # a third of the scenarios start far off the line: uneven solver work
+    a = SkidpadBatch(N, Tf, st, model=model)
+    b = SkidpadBatch(N, Tf, st, model=model)
+    us_a, it_a, st_a = [], torch.zeros(B, dtype=torch.int64, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+    for _ in range(nsteps):
+        us_a.append(a.step().clone()); it_a += a.iters; st_a = torch.maximum(st_a, a.status)
+    us_a = torch.stack(us_a)
+    xs_b, us_b = b.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    assert torch.equal(us_a, us_b)
+    assert torch.equal(a.state, b.state) and torch.equal(a.state, xs_b[-1])
+    assert torch.equal(a.lap, b.lap) and torch.equal(a.prev_progress, b.prev_progress)
+    assert torch.equal(it_a, b.iters.to(torch.int64)) and torch.equal(st_a, b.status)
+    assert int(it_a.max()) > (4 if model == "L" else 1) * max(1, int(it_a.min()))     # the work is uneven, so the order is not the identity
+    # the second call starts from the order the first one left
+    n2 = 1100 if model == "L" else 130         # L: longer than one chunk, so a chain of two launches
+    us_a2 = torch.stack([a.step().clone() for _ in range(n2)])
+    xs_b2, us_b2 = b.run(n2, record=True)
+    torch.cuda.synchronize()
+    assert torch.equal(us_a2, us_b2) and torch.equal(a.state, b.state)
+
+
 def test_out_of_reach_steering_start_is_relaxed_and_flagged(orc80):
     """A start steering angle beyond the bound by more than one step of full rate makes the reference's QP infeasible
     (acados raises there).  Library and checker both solve the problem with the bound widened along the way back inside
