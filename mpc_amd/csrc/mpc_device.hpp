@@ -25,42 +25,59 @@ __device__ __forceinline__ double bcast_pinned(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_max(double v)
+// Cross-lane arithmetic through DPP (data-parallel primitives: the operand of a VALU move comes from another lane of
+// the same 16-lane row) and v_readlane, not through ds_bpermute: an LDS round trip per step of a scan or reduction is a
+// chain of ~100-cycle latencies, a DPP step is one VALU issue.  dpp<CTRL>(v, fill) = v of the lane CTRL selects, or
+// `fill` where that lane lies outside the row.
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110;     // + n: lane i reads lane i + n / i - n of its row
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v, double fill)
 {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) v = fmax(v, __shfl_xor(v, d));
-    return v;
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v)
+
+struct OpSum { static __device__ __forceinline__ double id() { return 0.0; } static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ double id() { return -__builtin_huge_val(); } static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { static __device__ __forceinline__ double id() { return __builtin_huge_val(); } static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
+
+// Reduction over the 64 lanes, the same value in every lane: four DPP steps leave each row's result in its last lane,
+// the four row results are read out and combined.
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v)
 {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) v = fmin(v, __shfl_xor(v, d));
-    return v;
+    v = Op::f(v, dpp<DPP_ROW_SHR + 1>(v, Op::id()));
+    v = Op::f(v, dpp<DPP_ROW_SHR + 2>(v, Op::id()));
+    v = Op::f(v, dpp<DPP_ROW_SHR + 4>(v, Op::id()));
+    v = Op::f(v, dpp<DPP_ROW_SHR + 8>(v, Op::id()));
+    return Op::f(Op::f(bcast(v, 15), bcast(v, 31)), Op::f(bcast(v, 47), bcast(v, 63)));
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-// inclusive scans over the 64 lanes (callers zero the lanes that do not take part)
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
+
+// Inclusive scans over the 64 lanes (callers zero the lanes that do not take part): a scan inside each row of 16, then
+// the totals of the rows before (after) a lane's row are added.
 __device__ __forceinline__ double incl_prefix(double v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        double t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+    v += dpp<DPP_ROW_SHR + 1>(v, 0.0);
+    v += dpp<DPP_ROW_SHR + 2>(v, 0.0);
+    v += dpp<DPP_ROW_SHR + 4>(v, 0.0);
+    v += dpp<DPP_ROW_SHR + 8>(v, 0.0);
+    const double r0 = bcast(v, 15), r1 = bcast(v, 31), r2 = bcast(v, 47);
+    const double r01 = r0 + r1, r012 = r01 + r2;
+    return v + (lane < 16 ? 0.0 : lane < 32 ? r0 : lane < 48 ? r01 : r012);
 }
 __device__ __forceinline__ double incl_suffix(double v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        double t = __shfl_down(v, d);
-        if (lane + d < WAVE) v += t;
-    }
-    return v;
+    v += dpp<DPP_ROW_SHL + 1>(v, 0.0);
+    v += dpp<DPP_ROW_SHL + 2>(v, 0.0);
+    v += dpp<DPP_ROW_SHL + 4>(v, 0.0);
+    v += dpp<DPP_ROW_SHL + 8>(v, 0.0);
+    const double r3 = bcast(v, 48), r2 = bcast(v, 32), r1 = bcast(v, 16);
+    const double r32 = r3 + r2, r321 = r32 + r1;
+    return v + (lane >= 48 ? 0.0 : lane >= 32 ? r3 : lane >= 16 ? r32 : r321);
 }
 
 // ---------------------------------------------------------------- model pieces (uniform or per lane)

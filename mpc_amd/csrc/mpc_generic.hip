@@ -25,9 +25,18 @@ struct Vec {
     __device__ __forceinline__ double at(int i) const   // value of logical entry i (wave-uniform i)
     {
         if (R == 1) return rl(v[0], i);
-        return i < WAVE ? rl(v[0], i) : rl(v[R - 1], i - WAVE);
+        const double lo = rl(v[0], i & (WAVE - 1)), hi = rl(v[R - 1], i & (WAVE - 1));   // both halves, then a scalar select:
+        return i < WAVE ? lo : hi;                                                        // no branch in the callers' loops
     }
 };
+
+template <int R>
+__device__ __forceinline__ double rsel(const double (&x)[R], int i)   // logical entry i (wave-uniform) of a per-lane pair
+{
+    if (R == 1) return rl(x[0], i);
+    const double lo = rl(x[0], i & (WAVE - 1)), hi = rl(x[R - 1], i & (WAVE - 1));
+    return i < WAVE ? lo : hi;
+}
 
 template <int R>
 __device__ __forceinline__ Vec<R> vprefix(const Vec<R> &x, int lane)   // inclusive prefix sums in logical order
@@ -72,8 +81,10 @@ constexpr int LDLW = 8;
 template <int R>
 __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, int N, int lane, double (&dinv)[R])
 {
+
+    int ic[R];
 #pragma unroll
-    for (int q = 0; q < R; q++) dinv[q] = 1.0;
+    for (int q = 0; q < R; q++) { dinv[q] = 1.0; ic[q] = min(lane + WAVE * q, N - 1); }
 #pragma unroll 1
     for (int jb = 0; jb < N; jb += LDLW) {
         double a[LDLW][R];
@@ -82,55 +93,66 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int i = lane + WAVE * q, j = jb + w;
-                a[w][q] = (j < N && i >= j && i < N) ? M[j * LD + i] : 0.0;
+                const double m = M[min(j, N - 1) * LD + min(i, N - 1)];      // always read (clamped), then select: no branch
+                a[w][q] = (j < N && i >= j && i < N) ? m : 0.0;
             }
         }
+        // Earlier pivots, KU at a time: all their LDS reads are issued first (the scheduler otherwise waits for every
+        // broadcast read right where it is used), then the updates.  jb is a multiple of LDLW, hence of KU.
+        constexpr int KU = 4;
 #pragma unroll 1
-        for (int k = 0; k < jb; k++) {
-            const double ik = s_dinv[k];
-            double li[R];
+        for (int k0 = 0; k0 < jb; k0 += KU) {
+            // Entries that belong to no row or column of the matrix (i < jb, i >= N, jb + w >= N) are computed along with
+            // the rest and never used: a lane's accumulators depend on its own reads only, and the reads stay inside the
+            // LDS block (the pivot reciprocals follow the matrix).
+            double ikv[KU], mi[KU][R], cm[KU][LDLW];
+            const double *Mk = M + k0 * LD;
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int i = lane + WAVE * q;
-                li[q] = (i >= jb && i < N) ? M[k * LD + i] * ik : 0.0;
+            for (int u = 0; u < KU; u++) {
+                ikv[u] = s_dinv[k0 + u];
+#pragma unroll
+                for (int q = 0; q < R; q++) mi[u][q] = Mk[u * LD + ic[q]];
+#pragma unroll
+                for (int w = 0; w < LDLW; w++) cm[u][w] = Mk[u * LD + jb + w];   // wave-uniform address: LDS broadcast
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int w = 0; w < LDLW; w++) {
-                const double cjk = (jb + w < N) ? M[k * LD + jb + w] : 0.0;    // wave-uniform address: LDS broadcast
+            for (int u = 0; u < KU; u++) {
 #pragma unroll
-                for (int q = 0; q < R; q++) a[w][q] = fma(-li[q], cjk, a[w][q]);
+                for (int q = 0; q < R; q++) {
+                    const double li = mi[u][q] * ikv[u];
+#pragma unroll
+                    for (int w = 0; w < LDLW; w++) a[w][q] = fma(-li, cm[u][w], a[w][q]);
+                }
             }
         }
+        // The LDLW pivots of the block, without branches: a column or row beyond N computes on clamped reads into
+        // accumulators nobody uses, and only the stores are guarded.
 #pragma unroll
         for (int w = 0; w < LDLW; w++) {
             const int k = jb + w;
-            if (k < N) {
-                const double pivot = (R == 1 || k < WAVE) ? rl(a[w][0], k & (WAVE - 1)) : rl(a[w][R - 1], k - WAVE);
-                const double inv = fast_rcp(pivot);
-                double c[R], l[R];
+            const double pk = rsel<R>(a[w], min(k, N - 1));
+            const double pivot = (k < N) ? pk : 1.0;
+            const double inv = fast_rcp(pivot);
+            double c[R], l[R];
 #pragma unroll
-                for (int q = 0; q < R; q++) {
-                    const int i = lane + WAVE * q;
-                    c[q] = (i > k && i < N) ? a[w][q] : 0.0;
-                    l[q] = c[q] * inv;
-                    if (i == k) dinv[q] = inv;
-                }
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                c[q] = (i > k && i < N) ? a[w][q] : 0.0;
+                l[q] = c[q] * inv;
+                dinv[q] = (i == k && k < N) ? inv : dinv[q];
+            }
 #pragma unroll
-                for (int w2 = w + 1; w2 < LDLW; w2++) {
-                    const int j = jb + w2;
-                    if (j < N) {
-                        const double cjk = (R == 1 || j < WAVE) ? rl(c[0], j & (WAVE - 1)) : rl(c[R - 1], j - WAVE);
+            for (int w2 = w + 1; w2 < LDLW; w2++) {
+                const double cjk = rsel<R>(c, min(jb + w2, N - 1));
 #pragma unroll
-                        for (int q = 0; q < R; q++) a[w2][q] = fma(-l[q], cjk, a[w2][q]);
-                    }
-                }
+                for (int q = 0; q < R; q++) a[w2][q] = fma(-l[q], cjk, a[w2][q]);
+            }
 #pragma unroll
-                for (int q = 0; q < R; q++) {
-                    const int i = lane + WAVE * q;
-                    if (i == k) M[k * LD + k] = pivot;
-                    if (i > k && i < N) { M[k * LD + i] = c[q]; M[i * LD + k] = c[q]; }   // column k and its mirror
-                }
-                if (lane == 0) s_dinv[k] = inv;
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                if (i == k && k < N) { M[k * LD + k] = pivot; s_dinv[k] = inv; }
+                if (i > k && i < N) { M[k * LD + i] = c[q]; M[i * LD + k] = c[q]; }       // column k and its mirror
             }
         }
         wave_sync();
@@ -138,27 +160,59 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
 }
 
 template <int R>
-__device__ __forceinline__ Vec<R> lds_solve(const double *M, int LD, int N, int lane, const double (&dinv)[R], Vec<R> b)
+__device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_dinv, int LD, int N, int lane,
+                                            const double (&dinv)[R], Vec<R> b)
 {
     Vec<R> w = b;
-    for (int k = 0; k < N - 1; k++) {
-        const double wk = w.at(k) * fast_rcp(M[k * LD + k]);      // l(i,k) w_k = c(i,k) * (w_k / d_k)
+    constexpr int KU = 4;
+    int ic[R];
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = lane + WAVE * q;
-            if (i > k && i < N) w.v[q] = fma(-M[k * LD + i], wk, w.v[q]);
+    for (int q = 0; q < R; q++) ic[q] = min(lane + WAVE * q, N - 1);
+    // Forward.  The dependent chain per pivot is readlane -> multiply -> fma; column k and 1 / d(k) do not depend on
+    // it, so the LDS reads of KU pivots are issued together ahead of their chain steps.
+#pragma unroll 1
+    for (int k0 = 0; k0 < N - 1; k0 += KU) {
+        double dk[KU], m[KU][R];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int k = min(k0 + u, N - 1);
+            dk[u] = s_dinv[k];
+#pragma unroll
+            for (int q = 0; q < R; q++) m[u][q] = M[k * LD + ic[q]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int k = k0 + u;
+            const double wk = (k < N - 1) ? w.at(min(k, N - 1)) * dk[u] : 0.0;      // l(i,k) w_k = c(i,k) * (w_k / d_k)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                w.v[q] = fma(-((i > k && i < N) ? m[u][q] : 0.0), wk, w.v[q]);
+            }
         }
     }
-    // x_i = (w_i - sum_{k>i} c(k,i) x_k) / d_i, with c(k,i) read from the mirrored upper triangle
-    for (int k = N - 1; k > 0; k--) {
-        Vec<R> xs;
+    // Backward: x_i = (w_i - sum_{k>i} c(k,i) x_k) / d_i, with c(k,i) read from the mirrored upper triangle.
+#pragma unroll 1
+    for (int k0 = N - 1; k0 > 0; k0 -= KU) {
+        double dk[KU], m[KU][R];
 #pragma unroll
-        for (int q = 0; q < R; q++) xs.v[q] = w.v[q] * dinv[q];
-        const double xk = xs.at(k);
+        for (int u = 0; u < KU; u++) {
+            const int k = max(k0 - u, 0);
+            dk[u] = s_dinv[k];
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const int i = lane + WAVE * q;
-            if (i < k) w.v[q] = fma(-M[k * LD + i], xk, w.v[q]);
+            for (int q = 0; q < R; q++) m[u][q] = M[k * LD + ic[q]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int k = k0 - u;
+            const double xk = (k > 0) ? w.at(max(k, 0)) * dk[u] : 0.0;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                w.v[q] = fma(-((i < k) ? m[u][q] : 0.0), xk, w.v[q]);
+            }
         }
     }
 #pragma unroll
@@ -275,7 +329,6 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             stage_model(cfg, mp, s_p[k], a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr, N, k, &s_stage[k * STAGE_W]);
         for (int e = lane; e < N * LD; e += WAVE) M[e] = 0.0;
         wave_sync();
-
         // ------------------------------------------------------------ 3. condense into M (lower triangle) and g
         Vec<R> g;
         {
@@ -336,18 +389,37 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 }
                 wave_sync();
                 // M(i,j) += (W v_j)' v_i for j <= i < k (entries with i or j >= k are still zero)
-                for (int j = 0; j < k; j++) {
-                    double wj[6];
+                // Four columns per trip: their reads are issued together, then the updates, then the writes.  A weighted
+                // column entry is exactly zero where the weight is, and the columns j >= k of s_wv are zero (their lanes
+                // have not started), so everything is read and accumulated unconditionally; only the writes are guarded.
+                constexpr int CW = 4;
+#pragma unroll 1
+                for (int j0 = 0; j0 < k; j0 += CW) {
+                    double wj[CW][6], acc[CW][R];
 #pragma unroll
-                    for (int c = 0; c < 6; c++) wj[c] = (k == N || wq[c] != 0.0) ? s_wv[c * N + j] : 0.0;
+                    for (int u = 0; u < CW; u++) {
+                        const int j = min(j0 + u, N - 1);
 #pragma unroll
-                    for (int q = 0; q < R; q++) {
-                        const int i = lane + WAVE * q;
-                        if (i >= j && i < k) {
-                            double acc = M[j * LD + i];
+                        for (int c = 0; c < 6; c++) wj[u][c] = s_wv[c * N + j];
 #pragma unroll
-                            for (int c = 0; c < 6; c++) acc = fma(wj[c], v[q][c], acc);
-                            M[j * LD + i] = acc;
+                        for (int q = 0; q < R; q++) acc[u][q] = M[j * LD + min(lane + WAVE * q, N - 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CW; u++) {
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+#pragma unroll
+                            for (int c = 0; c < 6; c++) acc[u][q] = fma(wj[u][c], v[q][c], acc[u][q]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < CW; u++) {
+                        const int j = j0 + u;
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            const int i = lane + WAVE * q;
+                            if (j < k && i >= j && i < k) M[j * LD + i] = acc[u][q];
                         }
                     }
                 }
@@ -371,7 +443,6 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         }
         __threadfence_block();
         wave_sync();
-
         // ------------------------------------------------------------ 4. solve
         double up_d[R], lo_d[R];
         bool relaxed = false;
@@ -385,7 +456,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             Vec<R> rhs;
 #pragma unroll
             for (int q = 0; q < R; q++) rhs.v[q] = -g.v[q];
-            Vec<R> Uu = lds_solve<R>(M, LD, N, lane, dinv, rhs);
+            Vec<R> Uu = lds_solve<R>(M, s_dinv, LD, N, lane, dinv, rhs);
 #pragma unroll
             for (int q = 0; q < R; q++) if (!valid[q]) Uu.v[q] = 0.0;
             const Vec<R> vd = vprefix<R>(Uu, lane);
@@ -415,13 +486,40 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             Vec<R> U_last = U;
 #pragma unroll 1
             for (;;) {
+                // One pass over H (workspace, row j = column j) serves both the residual's H U and the Newton matrix
+                // K = H + diag(Du) + dt^2 sfx[max(i,j)] of this iterate (lower triangle into M; on the lower triangle
+                // max(i,j) = i).  Eight rows are requested together so that their memory latencies overlap.
+                Vec<R> Du, Dd;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    Du.v[q] = lpu.v[q] / tpu.v[q] + lmu.v[q] / tmu.v[q];
+                    Dd.v[q] = validd[q] ? lpd.v[q] / tpd.v[q] + lmd.v[q] / tmd.v[q] : 0.0;
+                }
+                const Vec<R> sfx = vsuffix<R>(Dd, lane);
                 Vec<R> hu;
 #pragma unroll
                 for (int q = 0; q < R; q++) hu.v[q] = 0.0;
-                for (int j = 0; j < N; j++) {
-                    const double uj = U.at(j);
+                constexpr int JU = 8;
+#pragma unroll 1
+                for (int j0 = 0; j0 < N; j0 += JU) {
+                    double h[JU][R];
 #pragma unroll
-                    for (int q = 0; q < R; q++) if (valid[q]) hu.v[q] = fma(Hg[j * N + lane + WAVE * q], uj, hu.v[q]);
+                    for (int u = 0; u < JU; u++) {
+#pragma unroll
+                        for (int q = 0; q < R; q++) h[u][q] = Hg[min(j0 + u, N - 1) * N + min(lane + WAVE * q, N - 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < JU; u++) {
+                        const int j = j0 + u;
+                        const double uj = (j < N) ? U.at(min(j, N - 1)) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < R; q++) {
+                            const int i = lane + WAVE * q;
+                            hu.v[q] = fma(valid[q] ? h[u][q] : 0.0, uj, hu.v[q]);
+                            if (j < N && i >= j && i < N) M[j * LD + i] = fma(dt2, sfx.v[q], h[u][q]) + (i == j ? Du.v[q] : 0.0);
+                        }
+                    }
                 }
                 const Vec<R> vd = vprefix<R>(U, lane);
                 Vec<R> lamd;
@@ -447,20 +545,6 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 if (iters >= cfg.max_iter) { status = 2; break; }
                 U_last = U;
                 res_prev = res;
-                Vec<R> Du, Dd;
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    Du.v[q] = lpu.v[q] / tpu.v[q] + lmu.v[q] / tmu.v[q];
-                    Dd.v[q] = validd[q] ? lpd.v[q] / tpd.v[q] + lmd.v[q] / tmd.v[q] : 0.0;
-                }
-                const Vec<R> sfx = vsuffix<R>(Dd, lane);
-                for (int j = 0; j < N; j++) {       // lower triangle: max(i,j) = i
-#pragma unroll
-                    for (int q = 0; q < R; q++) {
-                        const int i = lane + WAVE * q;
-                        if (i >= j && i < N) M[j * LD + i] = fma(dt2, sfx.v[q], Hg[j * N + i]) + (i == j ? Du.v[q] : 0.0);
-                    }
-                }
                 wave_sync();
                 lds_factor<R>(M, s_dinv, LD, N, lane, dinv);
                 Vec<R> dU, dtpu, dtmu, dlpu, dlmu, dtpd, dtmd, dlpd, dlmd;
@@ -492,7 +576,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                         const double wu = (lpu.v[q] * rppu.v[q] - rcpu.v[q]) / tpu.v[q] - (lmu.v[q] * rpmu.v[q] - rcmu.v[q]) / tmu.v[q];
                         rhs.v[q] = valid[q] ? -rd.v[q] - wu - dt * sw.v[q] : 0.0;
                     }
-                    dU = lds_solve<R>(M, LD, N, lane, dinv, rhs);
+                    dU = lds_solve<R>(M, s_dinv, LD, N, lane, dinv, rhs);
 #pragma unroll
                     for (int q = 0; q < R; q++) if (!valid[q]) dU.v[q] = 0.0;
                     const Vec<R> dvd = vprefix<R>(dU, lane);
