@@ -312,9 +312,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
                         if ((k < N ? wq[c] : wN[c]) != 0.0) {
-                            const double vc = v[c];
-#pragma unroll
-                            for (int i = 0; i < N; i++) nt.row[i] = fma(s_wv[c * N + i], vc, nt.row[i]);
+                            axpy_from_lds<N>(nt.row, &s_wv[c * N], v[c]);
                         }
                     }
                     wave_sync();

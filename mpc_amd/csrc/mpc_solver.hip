@@ -43,7 +43,7 @@ template <int N, int NF>
 __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const double *s_stage, const double *s_ref,
                                          double *s_wv, const double *s_We, const double (&wq)[6], double f35, double f45,
                                          const double (&c01s)[NF], const double (&c3)[NF], double (&xf)[NF][6],
-                                         double *Hrow, double (&g)[NF], double *gref_out)
+                                         double (&Hrow)[N], double (&g)[NF], double *gref_out)
 {
     const double dt = cfg.dt;
     const bool valid = lane < N;
@@ -109,9 +109,7 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             if (k == N || wq[c] != 0.0) {
-                const double vc = v[c];
-#pragma unroll
-                for (int i = 0; i < N; i++) Hrow[i] = fma(s_wv[c * N + i], vc, Hrow[i]);
+                axpy_from_lds<N>(Hrow, &s_wv[c * N], v[c]);
             }
         }
         wave_sync();

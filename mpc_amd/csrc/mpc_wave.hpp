@@ -7,6 +7,30 @@
 
 namespace mpc {
 
+// row[i] += src[i] * vc for i < N, with src in LDS at wave-uniform addresses (broadcast reads).  The reads go out in
+// groups of CH ahead of their multiply-adds: left to itself the scheduler waits for every read right where it is used,
+// and the accumulation becomes a chain of LDS round trips.
+template <int N>
+__device__ __forceinline__ void axpy_from_lds(double (&row)[N], const double *src, double vc)
+{
+    constexpr int CH = (N % 10 == 0) ? 10 : 8, G = N / CH;
+    static_assert(N % CH == 0, "horizon must be a multiple of 10 or of 8");
+    double t[2][CH];                       // the reads of group g + 1 are in flight while group g is accumulated
+#pragma unroll
+    for (int u = 0; u < CH; u++) t[0][u] = src[u];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g + 1 < G) {
+#pragma unroll
+            for (int u = 0; u < CH; u++) t[(g + 1) & 1][u] = src[(g + 1) * CH + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; u++) row[g * CH + u] = fma(t[g & 1][u], vc, row[g * CH + u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LDS hand-off between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
 // has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_sync()
