@@ -149,10 +149,15 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         // from hoisting the N loads out of the iteration loop into 2N registers per lane.
         // (loads are unconditional from a clamped row index and global-addressed: a predicated generic load costs a
         // branch and a flat instruction per entry)
+        // This lane's row of H goes into the Newton row once per iteration, all loads in flight together: the residual
+        // takes H U from it, and the Newton matrix is then built in place.
         const gdouble *Hr = (const gdouble *)opaque_uniform(Hm);
+#pragma unroll
+        for (int j = 0; j < N; j++) nt.row[j] = Hr[j * N + lc];
+        __builtin_amdgcn_sched_barrier(0);
         double hu = 0.0;
-#pragma unroll 10
-        for (int j = 0; j < N; j++) hu = fma(Hr[j * N + lc], bcast(U, j), hu);
+#pragma unroll
+        for (int j = 0; j < N; j++) hu = fma(nt.row[j], bcast(U, j), hu);
         if (!valid) hu = 0.0;
         const double vd = dt * incl_prefix(U, lane);
         const double lamd = validd ? (lpd - lmd) : 0.0;
@@ -192,16 +197,13 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         const double Du = lpu * itpu + lmu * itmu;
         const double Dd = validd ? lpd * itpd + lmd * itmd : 0.0;
         const double sfx = incl_suffix(Dd, lane);
-        const gdouble *Hk = (const gdouble *)opaque_uniform(Hm);
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const double sj = bcast(sfx, j);
-            double kij = Hk[j * N + lc];
-            if (!valid) kij = 0.0;
+            double kij = valid ? nt.row[j] : 0.0;
             kij = fma(dt2, (j > lane) ? sj : sfx, kij);
             if (j == lane) kij += Du;
             nt.row[j] = kij;
-            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight
         }
         nt.factor(lane);
         double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
