@@ -326,10 +326,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             double gq = valid ? g - hu : 0.0;        // (g + wr U) - (Gamma'W Gamma U + wr U)
+            const double wrd = opaque_value(wr);      // keeps the N one-hot addends out of (spilled) registers
 #pragma unroll
-            for (int i = 0; i < N; i++) {
-                if (i == lane) nt.row[i] += wr;
-                if (valid) Hw[i * N + lane] = nt.row[i];
+            for (int i = 0; i < N; i++) nt.row[i] += (i == lane) ? wrd : 0.0;
+            if (valid) {                            // one divergent region for all N stores, not one per entry
+                store_column<N>(Hw + lane, nt.row);
             }
             nt.factor(lane);
             double Un = valid ? nt.solve(-gq, lane) : 0.0;

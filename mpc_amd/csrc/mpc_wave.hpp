@@ -50,6 +50,34 @@ __device__ __forceinline__ const double *opaque_uniform(const double *p)
     return (const double *)(((unsigned long long)hi << 32) | lo);
 }
 
+// A copy of a per-lane value that the compiler cannot see through: what is computed from it stays where it is
+// written (no hoisting of a whole unrolled loop's worth of loop-invariant temporaries into spilled registers).
+__device__ __forceinline__ double opaque_value(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __hiloint2double(hi, lo);
+}
+
+// Stores row[0..N-1] of this lane to dst[i * N] (column `lane` of a row-major N x N matrix in global memory).  The
+// address is rebuilt every ten rows from a value the compiler cannot see through, so the rows in between are reached
+// by immediate offsets and no table of N hoisted addresses is kept (and spilled).
+template <int N>
+__device__ __forceinline__ void store_column(double *dst, const double (&row)[N])
+{
+    typedef __attribute__((address_space(1))) double gd;
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += 10) {
+        unsigned long long a = (unsigned long long)(dst + c0 * N);
+        unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        gd *p = (gd *)(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+        for (int u = 0; u < 10; u++)
+            if (c0 + u < N) p[u * N] = row[c0 + u];
+    }
+}
+
 // 1/x to ~1 ulp: hardware estimate plus two Newton steps (the pivots of an SPD factorisation are never 0/inf)
 __device__ __forceinline__ double fast_rcp(double x)
 {
