@@ -92,7 +92,7 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
 def measured_traffic(args):
     """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this process); only
     for the configuration those passes were taken on, else None."""
-    path = os.path.join(ROOT, "profiles", "r01d_c2_fused_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01e_c2_fused_hbm_traffic.json")
     if args.workload != "c2" or args.per_step_launch or args.steps != 1000 or args.batch not in (None, 4096) or not os.path.exists(path):
         return None
     with open(path) as fh:

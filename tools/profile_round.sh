@@ -13,4 +13,4 @@ run c4 --workload c4 --steps 100 --warmup 10 &&
 run c5 --workload c5 --steps 10 --warmup 2 &&
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --per-step-launch --steps 100 --warmup 20 > $O/pmc_fetch.json 2> $O/pmc_fetch.err &&
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o pmc_write -- python3 $R/bench.py --no-cpu-baseline --per-step-launch --steps 100 --warmup 20 > $O/pmc_write.json 2> $O/pmc_write.err &&
-python3 $R/tools/summarize_profiles.py $O $O/summary r01d && find $O -name "*_results.db" -delete && ls $O/summary
+python3 $R/tools/summarize_profiles.py $O $O/summary r01e && find $O -name "*_results.db" -delete && ls $O/summary
