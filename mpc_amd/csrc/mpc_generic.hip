@@ -70,16 +70,20 @@ template <int R> __device__ __forceinline__ double vmaxabs(const Vec<R> &x)
     return wave_max(m);
 }
 
-// LDL' of the symmetric matrix whose lower triangle sits in M (column-major with leading dimension LD: entry (row i,
-// column j) at M[j*LD + i], i >= j).  Column k keeps c(i,k) = d(k) l(i,k) with d(k) on the diagonal; the factor mirrors
-// it into the upper triangle (column i, row k) so that the backward substitution also reads thread-contiguously.
+// Packed lower triangle, column-major: entry (row i, column j), i >= j, sits at M[colp(j, N) + i]; column j holds its
+// N - j entries contiguously, so the lanes of a wave read a column without bank conflicts, and the whole matrix takes
+// N (N + 1) / 2 doubles (26 KB at N = 80: four waves per CU where a full square allows two).
+__device__ __forceinline__ int colp(int j, int N) { return (j * (2 * N - j - 1)) >> 1; }
+
+// LDL' of the symmetric matrix whose lower triangle sits in M (see colp).  Column k keeps c(i,k) = d(k) l(i,k) with d(k)
+// on the diagonal; the backward substitution gathers row k of it (one entry per column).
 // Left-looking in blocks of LDLW columns held in registers: every earlier pivot column is read from LDS once per block
 // (one coalesced read per lane plus LDLW broadcast reads for LDLW * R updates) instead of one read-modify-write of LDS
 // per updated entry.  s_dinv receives the reciprocal pivots.
 constexpr int LDLW = 8;
 
 template <int R>
-__device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, int N, int lane, double (&dinv)[R])
+__device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int N, int lane, double (&dinv)[R])
 {
 
     int ic[R];
@@ -93,7 +97,7 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int i = lane + WAVE * q, j = jb + w;
-                const double m = M[min(j, N - 1) * LD + min(i, N - 1)];      // always read (clamped), then select: no branch
+                const double m = M[colp(min(j, N - 1), N) + min(i, N - 1)];      // always read (clamped), then select: no branch
                 a[w][q] = (j < N && i >= j && i < N) ? m : 0.0;
             }
         }
@@ -106,14 +110,13 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
             // the rest and never used: a lane's accumulators depend on its own reads only, and the reads stay inside the
             // LDS block (the pivot reciprocals follow the matrix).
             double ikv[KU], mi[KU][R], cm[KU][LDLW];
-            const double *Mk = M + k0 * LD;
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 ikv[u] = s_dinv[k0 + u];
 #pragma unroll
-                for (int q = 0; q < R; q++) mi[u][q] = Mk[u * LD + ic[q]];
+                for (int q = 0; q < R; q++) mi[u][q] = M[colp(k0 + u, N) + ic[q]];
 #pragma unroll
-                for (int w = 0; w < LDLW; w++) cm[u][w] = Mk[u * LD + jb + w];   // wave-uniform address: LDS broadcast
+                for (int w = 0; w < LDLW; w++) cm[u][w] = M[colp(k0 + u, N) + jb + w];   // wave-uniform address: LDS broadcast
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -151,8 +154,8 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int i = lane + WAVE * q;
-                if (i == k && k < N) { M[k * LD + k] = pivot; s_dinv[k] = inv; }
-                if (i > k && i < N) { M[k * LD + i] = c[q]; M[i * LD + k] = c[q]; }       // column k and its mirror
+                if (i == k && k < N) { M[colp(k, N) + k] = pivot; s_dinv[k] = inv; }
+                if (i > k && i < N) M[colp(min(k, N - 1), N) + i] = c[q];
             }
         }
         wave_sync();
@@ -160,14 +163,14 @@ __device__ __forceinline__ void lds_factor(double *M, double *s_dinv, int LD, in
 }
 
 template <int R>
-__device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_dinv, int LD, int N, int lane,
+__device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_dinv, int N, int lane,
                                             const double (&dinv)[R], Vec<R> b)
 {
     Vec<R> w = b;
     constexpr int KU = 4;
-    int ic[R];
+    int ic[R], cpl[R];
 #pragma unroll
-    for (int q = 0; q < R; q++) ic[q] = min(lane + WAVE * q, N - 1);
+    for (int q = 0; q < R; q++) { ic[q] = min(lane + WAVE * q, N - 1); cpl[q] = colp(ic[q], N); }
     // Forward.  The dependent chain per pivot is readlane -> multiply -> fma; column k and 1 / d(k) do not depend on
     // it, so the LDS reads of KU pivots are issued together ahead of their chain steps.
 #pragma unroll 1
@@ -178,7 +181,7 @@ __device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_din
             const int k = min(k0 + u, N - 1);
             dk[u] = s_dinv[k];
 #pragma unroll
-            for (int q = 0; q < R; q++) m[u][q] = M[k * LD + ic[q]];
+            for (int q = 0; q < R; q++) m[u][q] = M[colp(k, N) + ic[q]];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -192,7 +195,7 @@ __device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_din
             }
         }
     }
-    // Backward: x_i = (w_i - sum_{k>i} c(k,i) x_k) / d_i, with c(k,i) read from the mirrored upper triangle.
+    // Backward: x_i = (w_i - sum_{k>i} c(k,i) x_k) / d_i.
 #pragma unroll 1
     for (int k0 = N - 1; k0 > 0; k0 -= KU) {
         double dk[KU], m[KU][R];
@@ -201,7 +204,7 @@ __device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_din
             const int k = max(k0 - u, 0);
             dk[u] = s_dinv[k];
 #pragma unroll
-            for (int q = 0; q < R; q++) m[u][q] = M[k * LD + ic[q]];
+            for (int q = 0; q < R; q++) m[u][q] = M[cpl[q] + k];      // c(k,i), i = this lane's column: a gather along row k
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     const int s = a.order ? a.order[blockIdx.x] : blockIdx.x;      // scenario this wave advances (grid = B workgroups)
     const int lane = threadIdx.x;
     const int N = cfg.N;
-    const int LD = N | 1;                 // odd leading dimension: the one strided access per pivot is 2-way at worst
+    const int NM = (N * (N + 1)) >> 1;    // doubles of the packed lower triangle
     extern __shared__ double lds[];
     double *s_ref = lds, *s_p = s_ref + 3 * (N + 1), *s_stage = s_p + (N + 1), *s_wv = s_stage + N * STAGE_W;
-    double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_dinv = M + (size_t)N * LD, *s_ekf = s_dinv + N;
+    double *s_We = s_wv + 6 * N, *M = s_We + 36, *s_dinv = M + NM, *s_ekf = s_dinv + N;
     if (lane < 36) s_We[lane] = a.cost_scen ? a.cost_scen[43 * (size_t)s + 7 + lane] : cfg.We[lane];
 
     ModelParams mp;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;
         for (int k = lane; k < N; k += WAVE)
             stage_model(cfg, mp, s_p[k], a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr, N, k, &s_stage[k * STAGE_W]);
-        for (int e = lane; e < N * LD; e += WAVE) M[e] = 0.0;
+        for (int e = lane; e < NM; e += WAVE) M[e] = 0.0;
         wave_sync();
         // ------------------------------------------------------------ 3. condense into M (lower triangle) and g
         Vec<R> g;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
                         for (int c = 0; c < 6; c++) wj[u][c] = s_wv[c * N + j];
 #pragma unroll
-                        for (int q = 0; q < R; q++) acc[u][q] = M[j * LD + min(lane + WAVE * q, N - 1)];
+                        for (int q = 0; q < R; q++) acc[u][q] = M[colp(j, N) + min(lane + WAVE * q, N - 1)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
                         for (int q = 0; q < R; q++) {
                             const int i = lane + WAVE * q;
-                            if (j < k && i >= j && i < k) M[j * LD + i] = acc[u][q];
+                            if (j < k && i >= j && i < k) M[colp(j, N) + i] = acc[u][q];
                         }
                     }
                 }
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
         for (int q = 0; q < R; q++) {
             const int i = lane + WAVE * q;
-            if (i < N) M[i * LD + i] += wr;
+            if (i < N) M[colp(i, N) + i] += wr;
             else g.v[q] = 0.0;
         }
         wave_sync();
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int i = lane + WAVE * q;
-                if (i >= j && i < N) { const double h = M[j * LD + i]; Hg[j * N + i] = h; Hg[i * N + j] = h; }
+                if (i >= j && i < N) { const double h = M[colp(j, N) + i]; Hg[j * N + i] = h; Hg[i * N + j] = h; }
             }
         }
         __threadfence_block();
@@ -449,14 +452,14 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
         for (int q = 0; q < R; q++) steer_bounds(xh5, dmax, umax, dt, lane + WAVE * q, up_d[q], lo_d[q], relaxed);
         double dinv[R];
-        lds_factor<R>(M, s_dinv, LD, N, lane, dinv);
+        lds_factor<R>(M, s_dinv, N, lane, dinv);
         Vec<R> U;
         int iters = 0, status = 0, constrained = 0;
         {
             Vec<R> rhs;
 #pragma unroll
             for (int q = 0; q < R; q++) rhs.v[q] = -g.v[q];
-            Vec<R> Uu = lds_solve<R>(M, s_dinv, LD, N, lane, dinv, rhs);
+            Vec<R> Uu = lds_solve<R>(M, s_dinv, N, lane, dinv, rhs);
 #pragma unroll
             for (int q = 0; q < R; q++) if (!valid[q]) Uu.v[q] = 0.0;
             const Vec<R> vd = vprefix<R>(Uu, lane);
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                         for (int q = 0; q < R; q++) {
                             const int i = lane + WAVE * q;
                             hu.v[q] = fma(valid[q] ? h[u][q] : 0.0, uj, hu.v[q]);
-                            if (j < N && i >= j && i < N) M[j * LD + i] = fma(dt2, sfx.v[q], h[u][q]) + (i == j ? Du.v[q] : 0.0);
+                            if (j < N && i >= j && i < N) M[colp(j, N) + i] = fma(dt2, sfx.v[q], h[u][q]) + (i == j ? Du.v[q] : 0.0);
                         }
                     }
                 }
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 U_last = U;
                 res_prev = res;
                 wave_sync();
-                lds_factor<R>(M, s_dinv, LD, N, lane, dinv);
+                lds_factor<R>(M, s_dinv, N, lane, dinv);
                 Vec<R> dU, dtpu, dtmu, dlpu, dlmu, dtpd, dtmd, dlpd, dlmd;
 #pragma unroll
                 for (int q = 0; q < R; q++) {
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                         const double wu = (lpu.v[q] * rppu.v[q] - rcpu.v[q]) / tpu.v[q] - (lmu.v[q] * rpmu.v[q] - rcmu.v[q]) / tmu.v[q];
                         rhs.v[q] = valid[q] ? -rd.v[q] - wu - dt * sw.v[q] : 0.0;
                     }
-                    dU = lds_solve<R>(M, s_dinv, LD, N, lane, dinv, rhs);
+                    dU = lds_solve<R>(M, s_dinv, N, lane, dinv, rhs);
 #pragma unroll
                     for (int q = 0; q < R; q++) if (!valid[q]) dU.v[q] = 0.0;
                     const Vec<R> dvd = vprefix<R>(dU, lane);
@@ -741,8 +744,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 
 static size_t any_lds_bytes(int N, int mode)
 {
-    const int LD = N | 1;
-    return sizeof(double) * ((size_t)4 * (N + 1) + (size_t)N * STAGE_W + 6 * (size_t)N + 36 + (size_t)N * LD + (size_t)N +
+    return sizeof(double) * ((size_t)4 * (N + 1) + (size_t)N * STAGE_W + 6 * (size_t)N + 36 + (size_t)(N * (N + 1) / 2) + (size_t)N +
                              (mode == MODE_OFL ? EKF_LDS : 0));
 }
 
