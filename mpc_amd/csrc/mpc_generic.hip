@@ -276,6 +276,11 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     int iters_tot = 0, status_max = 0, nconstr = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     double *Hg = a.Hws + (size_t)s * N * N;
+    // closed loops start the interior point from the previous step's solve when that step needed one too (record:
+    // inputs and the four multiplier vectors, [5][WS], then a validity flag; see interior_point())
+    constexpr int WS = 2 * WAVE;
+    double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
+    bool warm_ok = warm_rec && warm_rec[5 * WS] == 1.0;
 
 #pragma unroll 1
     for (int t = 0; t < nsteps; t++) {
@@ -484,6 +489,35 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
                 lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
             }
+            bool warm = warm_ok;
+            if (warm) {
+                // the previous solve moved one stage ahead, slacks pushed back inside, multipliers lifted to a common
+                // small complementarity target (same rule as interior_point())
+                const double delta = 3e-3;
+                double a0[R], a1[R], a2[R], a3[R];
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int i = lane + WAVE * q, ii = min(i, N - 1);
+                    const int iu = (i < N - 1) ? ii + 1 : ii, id = (i < N - 2) ? ii + 1 : ii;
+                    const double u0 = warm_rec[iu];
+                    a0[q] = warm_rec[WS + iu]; a1[q] = warm_rec[2 * WS + iu];
+                    a2[q] = warm_rec[3 * WS + id]; a3[q] = warm_rec[4 * WS + id];
+                    U.v[q] = valid[q] ? fmin(fmax(u0, -umax), umax) : 0.0;
+                }
+                const Vec<R> vd0 = vprefix<R>(U, lane);
+                const double mu0 = delta * 0.01 * gscale;
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if (valid[q]) {
+                        tpu.v[q] = fmax(umax - U.v[q], delta * 2.0 * umax); tmu.v[q] = fmax(umax + U.v[q], delta * 2.0 * umax);
+                        lpu.v[q] = fmax(a0[q], mu0 / tpu.v[q]); lmu.v[q] = fmax(a1[q], mu0 / tmu.v[q]);
+                    }
+                    if (validd[q]) {
+                        tpd.v[q] = fmax(up_d[q] - dt * vd0.v[q], delta * 2.0 * dmax); tmd.v[q] = fmax(dt * vd0.v[q] - lo_d[q], delta * 2.0 * dmax);
+                        lpd.v[q] = fmax(a2[q], mu0 / tpd.v[q]); lmd.v[q] = fmax(a3[q], mu0 / tmd.v[q]);
+                    }
+                }
+            }
             const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
             double res_prev = 1e300;
             Vec<R> U_last = U;
@@ -542,6 +576,20 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 }
                 mu = wave_sum(musum) * inv_nc;
                 res = fmax(vmaxabs<R>(rd) / gscale, wave_max(rpmax));
+                if (warm && iters == 0 && res > IPM_WARM_RES_MAX) {
+                    // the problem moved too far from the previous one: fall back to the cold start
+                    warm = false;
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        U.v[q] = 0.0;
+                        tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
+                        lpu.v[q] = valid[q] ? lam0 : 0.0; lmu.v[q] = lpu.v[q];
+                        tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
+                        lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
+                    }
+                    U_last = U;
+                    continue;
+                }
                 if (mu <= cfg.tol_mu && (res <= cfg.tol_res || res >= 0.5 * res_prev)) break;
                 if (mu <= 1e-3 * cfg.tol_mu) { if (res > 1e3 * cfg.tol_res) status = 2; break; }   // see interior_point()
                 if (!(mu == mu)) { U = U_last; status = 2; break; }
@@ -650,7 +698,19 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 }
                 iters++;
             }
-        }
+            if (warm_rec) {
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int i = lane + WAVE * q;
+                    if (valid[q]) {
+                        warm_rec[i] = U.v[q]; warm_rec[WS + i] = lpu.v[q]; warm_rec[2 * WS + i] = lmu.v[q];
+                        warm_rec[3 * WS + i] = lpd.v[q]; warm_rec[4 * WS + i] = lmd.v[q];
+                    }
+                }
+            }
+            warm_ok = warm_rec != nullptr && status == 0;
+        } else
+            warm_ok = false;
 
         if (relaxed) status = max(status, 4);
         // ------------------------------------------------------------ 5. outputs, prediction, plant, estimator
@@ -731,6 +791,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         }
     }
     if (lane == 0) {
+        if (warm_rec) warm_rec[5 * WS] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
         if (a.work_out) a.work_out[s] = iters_tot;
         if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;

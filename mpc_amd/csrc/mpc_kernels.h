@@ -11,7 +11,8 @@
 
 namespace mpc {
 
-constexpr int IPM_WARM_DOUBLES = 6 * 64;   // interior-point warm-start record per scenario (see IpmParams)
+constexpr int IPM_WARM_DOUBLES = 6 * 128;  // interior-point warm-start record per scenario (see IpmParams); the any-horizon
+                                           // kernel keeps [5][128] and its flag at 5 * 128, the register kernels [5][64] and 5 * 64
 
 enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2, MODE_OFL = 3 };   // OFL: step planner on the EKF estimate
 
