@@ -283,17 +283,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 if (a.sh_mask & (1 << c)) {
                     const double *Kc = GENERAL ? a.sh_Kref + (size_t)c * N * N : s_K + ci * N * N;
                     const double *rc = s_ref + c * (N + 1) + 1;      // reference of stage kk + 1, read as an LDS broadcast
-                    if (valid) {
-#pragma unroll
-                        for (int kk = 0; kk < N; kk++) {
-                            acc = fma(Kc[kk * N + lane], rc[kk], acc);
-                            if ((kk % 10) == 9) __builtin_amdgcn_sched_barrier(0);   // at most 20 LDS reads in flight
-                        }
-                    }
+                    acc += dot_column<N>(Kc, rc, valid ? lane : 0);        // lanes beyond N repeat column 0 and are zeroed below
                     ci++;
                 }
             }
-            const double Uu = acc;
+            const double Uu = valid ? acc : 0.0;
             const double vd = dt * incl_prefix(Uu, lane);
             bool ok = fabs(Uu) <= umax;
             if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);

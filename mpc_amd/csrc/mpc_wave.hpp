@@ -31,6 +31,35 @@ __device__ __forceinline__ void axpy_from_lds(double (&row)[N], const double *sr
     }
 }
 
+// sum_k K[k * N + col] * r[k], k < N: column `col` of K against a wave-uniform vector (r in LDS: broadcast reads).  The
+// reads go out one group ahead of the multiply-adds, which run on two accumulators: issued one by one they form a
+// chain of N memory round trips and N dependent fma latencies.
+template <int N>
+__device__ __forceinline__ double dot_column(const double *K, const double *r, int col)
+{
+    constexpr int CH = (N % 10 == 0) ? 10 : 8, G = N / CH;
+    static_assert(N % CH == 0, "horizon must be a multiple of 10 or of 8");
+    double kv[2][CH], rv[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++) { kv[0][u] = K[u * N + col]; rv[0][u] = r[u]; }
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g + 1 < G) {
+#pragma unroll
+            for (int u = 0; u < CH; u++) { kv[(g + 1) & 1][u] = K[((g + 1) * CH + u) * N + col]; rv[(g + 1) & 1][u] = r[(g + 1) * CH + u]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; u += 2) {
+            acc0 = fma(kv[g & 1][u], rv[g & 1][u], acc0);
+            acc1 = fma(kv[g & 1][u + 1], rv[g & 1][u + 1], acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
+}
+
 // LDS hand-off between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
 // has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_sync()
