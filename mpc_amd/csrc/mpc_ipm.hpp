@@ -197,12 +197,13 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         const double Du = lpu * itpu + lmu * itmu;
         const double Dd = validd ? lpd * itpd + lmd * itmd : 0.0;
         const double sfx = incl_suffix(Dd, lane);
+        // Dd >= 0, so the suffix sums do not increase with the stage and Sfx[max(i,j)] = min(Sfx[i], Sfx[j]): one v_min
+        // with the broadcast value instead of a compare-and-select pair per entry (and symmetric whatever the rounding
+        // of the scan).  Lanes beyond N carry a copy of row 0: finite values nobody reads.
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const double sj = bcast(sfx, j);
-            double kij = valid ? nt.row[j] : 0.0;
-            kij = fma(dt2, (j > lane) ? sj : sfx, kij);
-            if (j == lane) kij += Du;
+            double kij = fma(dt2, fmin(sfx, bcast(sfx, j)), nt.row[j]);
+            kij += (j == lane) ? Du : 0.0;
             nt.row[j] = kij;
         }
         nt.factor(lane);
