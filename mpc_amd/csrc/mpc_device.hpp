@@ -53,6 +53,15 @@ __device__ __forceinline__ double wave_reduce(double v)
     v = Op::f(v, dpp<DPP_ROW_SHR + 8>(v, Op::id()));
     return Op::f(Op::f(bcast(v, 15), bcast(v, 31)), Op::f(bcast(v, 47), bcast(v, 63)));
 }
+// A copy of a per-lane integer that the compiler cannot see through.  Comparisons of the lane index with unrolled loop
+// counters are loop-invariant for the caller's iteration loop; hoisted, their N mask pairs overflow the SGPR file and
+// come back through v_writelane / v_readlane spills, which costs more than recomputing each compare where it is used.
+__device__ __forceinline__ int opaque_int(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }

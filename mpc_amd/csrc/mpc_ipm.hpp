@@ -18,8 +18,9 @@ struct Newton {
     double row[N];
     double dinv;
 
-    __device__ __forceinline__ void factor(int lane)
+    __device__ __forceinline__ void factor(int lane_in)
     {
+        const int lane = opaque_int(lane_in);
         dinv = 1.0;
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -46,20 +47,20 @@ struct Newton {
     }
 
     // solves (L D L') x = b; b, x one entry per lane
-    __device__ __forceinline__ double solve(double b, int lane) const
+    __device__ __forceinline__ double solve(double b, int lane_in) const
     {
+        const int lane = opaque_int(lane_in);
         double w = b;
 #pragma unroll
         for (int k = 0; k < N - 1; k++) {
-            const double wk = bcast(w, k);
-            w = fma(-row[k], lane > k ? wk : 0.0, w);   // mask the broadcast value, not the row entry: a masked copy
-                                                        // of the row is loop-invariant and would be hoisted into 2N registers
+            const double t = fma(-row[k], bcast(w, k), w);     // the broadcast is the fma's scalar operand; the select is
+            w = lane > k ? t : w;                              // on the result (a masked copy of the row would be hoisted)
             if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = N - 1; k > 0; k--) {
-            const double xk = bcast(w * dinv, k);
-            w = fma(-row[k], lane < k ? xk : 0.0, w);
+            const double t = fma(-row[k], bcast(w * dinv, k), w);
+            w = lane < k ? t : w;
             if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         return w * dinv;
@@ -197,13 +198,14 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         const double Du = lpu * itpu + lmu * itmu;
         const double Dd = validd ? lpd * itpd + lmd * itmd : 0.0;
         const double sfx = incl_suffix(Dd, lane);
+        const int lane_k = opaque_int(lane);
         // Dd >= 0, so the suffix sums do not increase with the stage and Sfx[max(i,j)] = min(Sfx[i], Sfx[j]): one v_min
         // with the broadcast value instead of a compare-and-select pair per entry (and symmetric whatever the rounding
         // of the scan).  Lanes beyond N carry a copy of row 0: finite values nobody reads.
 #pragma unroll
         for (int j = 0; j < N; j++) {
             double kij = fma(dt2, fmin(sfx, bcast(sfx, j)), nt.row[j]);
-            kij += (j == lane) ? Du : 0.0;
+            kij += (j == lane_k) ? Du : 0.0;
             nt.row[j] = kij;
         }
         nt.factor(lane);
