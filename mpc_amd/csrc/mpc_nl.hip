@@ -326,9 +326,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             double gq = valid ? g - hu : 0.0;        // (g + wr U) - (Gamma'W Gamma U + wr U)
-            const double wrd = opaque_value(wr);      // keeps the N one-hot addends out of (spilled) registers
+            const double wrd = opaque_value(wr);      // keeps the N one-hot addends (and their N compare masks)
+            const int lane_d = opaque_int(lane);      // out of hoisted, spilled registers
 #pragma unroll
-            for (int i = 0; i < N; i++) nt.row[i] += (i == lane) ? wrd : 0.0;
+            for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
             if (valid) {                            // one divergent region for all N stores, not one per entry
                 store_column<N>(Hw + lane, nt.row);
             }

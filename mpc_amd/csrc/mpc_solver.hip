@@ -315,9 +315,10 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             condense<N, 1>(cfg, lane, s_stage, s_ref, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
             g = gs[0];
             const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
-            const double wrd = opaque_value(wr);      // keeps the N one-hot addends out of (spilled) registers
+            const double wrd = opaque_value(wr);      // keeps the N one-hot addends (and their N compare masks)
+            const int lane_d = opaque_int(lane);      // out of hoisted, spilled registers
 #pragma unroll
-            for (int i = 0; i < N; i++) nt.row[i] += (i == lane) ? wrd : 0.0;
+            for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
             if (valid) {                            // one divergent region for all N stores, not one per entry
                 store_column<N>(Hw + lane, nt.row);
             }
