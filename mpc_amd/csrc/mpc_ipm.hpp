@@ -1,6 +1,7 @@
 // Register-resident Newton systems and the interior-point iteration of the condensed MPC problem (gfx950, wave64):
 // shared by the linear-model kernels (mpc_solver.hip) and the nonlinear SQP kernel (mpc_nl.hip).
 #pragma once
+#include <utility>
 #include "mpc_wave.hpp"
 
 #pragma clang fp contract(fast)
@@ -8,6 +9,7 @@
 namespace mpc {
 
 typedef __attribute__((address_space(1))) double gdouble;   // a double in global memory
+typedef __attribute__((address_space(3))) double ldouble;   // a double in LDS
 
 // ------------------------------------------------------------------------------------------------
 template <int N>
@@ -18,32 +20,74 @@ struct Newton {
     double row[N];
     double dinv;
 
-    __device__ __forceinline__ void factor(int lane_in)
+    // The update row[j] -= l * c(j) needs entry j of the pivot column in every lane.  Two ways, used side by side so that
+    // neither the VALU (two v_readlane issues per value) nor the LDS pipe (shared by the waves of the CU) carries all
+    // of it: the first half of the columns takes the value from the owning lane's register through v_readlane, the
+    // second half reads it back from a 64-double LDS slot `bc` (any per-wave LDS area that is dead during the
+    // factorisation) that every lane has written its entry to.  The LDS reads are issued a group ahead.
+    template <int K, bool USE_LDS>
+    __device__ __forceinline__ void eliminate(int lane, int lane_in, ldouble *bc)
     {
-        const int lane = opaque_int(lane_in);
-        dinv = 1.0;
+        constexpr int LG = 8;                                             // LDS group
+        constexpr int M = N - 1 - K;                                      // entries to update
+        constexpr int NL = (USE_LDS && M >= 2 * LG) ? ((M / 2) / LG) * LG : 0;       // how many of them (the last ones) go through LDS
+        constexpr int JL = N - NL;                                        // first LDS column
+        const double c = row[K];                 // column K of the trailing matrix, one entry per lane
+        if (NL) bc[lane_in] = c;
+        const double inv = fast_rcp(bcast(c, K));
+        const bool below = lane > K;
+        const double l = below ? c * inv : 0.0;
+        if (lane == K) dinv = inv;
+        double t[2][LG];
+        if (NL) {
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            const double c = row[k];                 // column k of the trailing matrix, one entry per lane
-            const double inv = fast_rcp(bcast(c, k));
-            const bool below = lane > k;
-            const double l = below ? c * inv : 0.0;
-            if (lane == k) dinv = inv;
-            // groups of 4: broadcast four pivot-column entries, then the four updates that use them
+            for (int u = 0; u < LG; u++) t[0][u] = bc[JL + u];
+        }
+        // groups of 4: broadcast four pivot-column entries, then the four updates that use them
 #pragma unroll
-            for (int j0 = k + 1; j0 < N; j0 += 4) {
-                double cj[4];
+        for (int j0 = K + 1; j0 < JL; j0 += 4) {
+            double cj[4];
 #pragma unroll
-                for (int g = 0; g < 4; g++)
-                    if (j0 + g < N) cj[g] = bcast_pinned(c, j0 + g);
+            for (int g = 0; g < 4; g++)
+                if (j0 + g < JL) cj[g] = bcast_pinned(c, j0 + g);
 #pragma unroll
-                for (int g = 0; g < 4; g++)
-                    if (j0 + g < N) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
-                __builtin_amdgcn_sched_barrier(0);                           // keep readlane results (SGPRs) short-lived
+            for (int g = 0; g < 4; g++)
+                if (j0 + g < JL) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
+            __builtin_amdgcn_sched_barrier(0);                           // keep readlane results (SGPRs) short-lived
+        }
+#pragma unroll
+        for (int g0 = 0; g0 < NL; g0 += LG) {
+            const int cur = (g0 / LG) & 1;
+            if (g0 + LG < NL) {
+#pragma unroll
+                for (int u = 0; u < LG; u++) t[cur ^ 1][u] = bc[JL + g0 + LG + u];
             }
-            if (below) row[k] = l;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LG; u++) row[JL + g0 + u] = fma(-l, t[cur][u], row[JL + g0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (below) row[K] = l;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <bool USE_LDS, int... Ks>
+    __device__ __forceinline__ void eliminate_all(int lane, int lane_in, ldouble *bc, std::integer_sequence<int, Ks...>)
+    {
+        (eliminate<Ks, USE_LDS>(lane, lane_in, bc), ...);
+    }
+
+    // The update row[j] -= l * c(j) needs entry j of the pivot column in every lane.  Two ways, used side by side so that
+    // neither the VALU (two v_readlane issues per value) nor the LDS pipe (shared by the waves of the CU) carries all
+    // of it: the first half of the columns takes the value from the owning lane's register through v_readlane, the
+    // second half reads it back from a 64-double LDS slot `bc` (any per-wave LDS area that is dead during the
+    // factorisation) that every lane has written its entry to.  The LDS reads are issued a group ahead.
+    // USE_LDS = false keeps every broadcast on v_readlane (for kernels whose LDS pipe is the busier one).
+    template <bool USE_LDS = true>
+    __device__ __forceinline__ void factor(int lane_in, ldouble *bc)
+    {
+        dinv = 1.0;
+        eliminate_all<USE_LDS>(opaque_int(lane_in), lane_in, bc, std::make_integer_sequence<int, N>{});
     }
 
     // solves (L D L') x = b; b, x one entry per lane
@@ -101,7 +145,7 @@ constexpr double IPM_WARM_RES_MAX = 0.05;   // largest relative residual a warm 
 // target as its register budget instead of the loosest budget among all callers.
 template <int N, int TAG>
 static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double up_d,
-                                                 double lo_d)
+                                                 double lo_d, ldouble *bc)
 {
     Newton<N> nt;
     double U, mu, res;
@@ -208,7 +252,8 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
             kij += (j == lane_k) ? Du : 0.0;
             nt.row[j] = kij;
         }
-        nt.factor(lane);
+        nt.template factor<TAG == 2>(lane, bc);       // TAG 2 is the fixed-model kernel; the others condense per scenario,
+                                                      // which loads the LDS pipe already
         double dU = 0, dtpu = 0, dtmu = 0, dlpu = 0, dlmu = 0, dtpd = 0, dtmd = 0, dlpd = 0, dlmd = 0;
         const bool safe = iters >= IPM_SAFE_AFTER;
         double sigmu = safe ? 0.25 * mu : 0.0, alpha = 1.0;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             if (valid) {                            // one divergent region for all N stores, not one per entry
                 store_column<N>(Hw + lane, nt.row);
             }
-            nt.factor(lane);
+            nt.template factor<false>(lane, (ldouble *)s_wv);
             double Un = valid ? nt.solve(-gq, lane) : 0.0;
             const double vd = dt * incl_prefix(Un, lane);
             bool ok = fabs(Un) <= umax;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 // closed-loop step's moved one stage ahead
                 const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
                 const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm};
-                const IpmResult r = interior_point<N, 3>(prm, lane, Hw, gq, up_d, lo_d);
+                const IpmResult r = interior_point<N, 3>(prm, lane, Hw, gq, up_d, lo_d, (ldouble *)s_wv);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
                 warm_ok = (warm_rec != nullptr) && r.status == 0;

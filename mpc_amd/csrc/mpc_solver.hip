@@ -323,7 +323,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 store_column<N>(Hw + lane, nt.row);
             }
             if (!valid) g = 0.0;
-            nt.factor(lane);
+            nt.template factor<false>(lane, (ldouble *)s_wv);
             const double Uu = valid ? nt.solve(-g, lane) : 0.0;
             const double vd = dt * incl_prefix(Uu, lane);
             bool ok = fabs(Uu) <= umax;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         if (constrained) {
             // closed loops start the interior point from the previous step's solve when that step needed one too
             const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0};
-            const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d);
+            const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)(GENERAL ? s_wv : s_ref));   // both areas are dead by now
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
             warm_ok = (warm_rec != nullptr) && r.status == 0;
         } else
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, doubl
         if (i == lane) nt.row[i] += dt * cfg.w[6];
         if (valid) H[i * N + lane] = nt.row[i];
     }
-    nt.factor(lane);
+    nt.template factor<false>(lane, (ldouble *)s_wv);
 #pragma unroll 1
     for (int f = 0; f < 5; f++) {
         double gf = g[0];
