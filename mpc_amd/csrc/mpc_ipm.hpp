@@ -20,17 +20,19 @@ struct Newton {
     double row[N];
     double dinv;
 
-    // The update row[j] -= l * c(j) needs entry j of the pivot column in every lane.  Two ways, used side by side so that
-    // neither the VALU (two v_readlane issues per value) nor the LDS pipe (shared by the waves of the CU) carries all
-    // of it: the first half of the columns takes the value from the owning lane's register through v_readlane, the
-    // second half reads it back from a 64-double LDS slot `bc` (any per-wave LDS area that is dead during the
-    // factorisation) that every lane has written its entry to.  The LDS reads are issued a group ahead.
+    // Elimination step K of the LDL' factorisation.  The update row[j] -= l * c(j) needs entry j of the pivot column in
+    // every lane: from the owning lane's register through v_readlane (two VALU issues per value, on a VALU that is the
+    // bottleneck of the interior point), or read back from a 64-double LDS slot `bc` (any per-wave LDS area that is dead
+    // during the factorisation) that every lane has written its entry to; the LDS reads are issued a group ahead of
+    // their multiply-adds.  With USE_LDS all but the first few columns of a step (a multiple of the group size goes
+    // through LDS) take the second way; measured on the fixed-model kernel: 9% more throughput with every wave in the
+    // interior point (c4 workload), 3% on c2.
     template <int K, bool USE_LDS>
     __device__ __forceinline__ void eliminate(int lane, int lane_in, ldouble *bc)
     {
         constexpr int LG = 8;                                             // LDS group
         constexpr int M = N - 1 - K;                                      // entries to update
-        constexpr int NL = (USE_LDS && M >= 2 * LG) ? ((M / 2) / LG) * LG : 0;       // how many of them (the last ones) go through LDS
+        constexpr int NL = (USE_LDS && M >= 2 * LG) ? (M / LG) * LG : 0;             // how many of them (the last ones) go through LDS
         constexpr int JL = N - NL;                                        // first LDS column
         const double c = row[K];                 // column K of the trailing matrix, one entry per lane
         if (NL) bc[lane_in] = c;
@@ -77,11 +79,6 @@ struct Newton {
         (eliminate<Ks, USE_LDS>(lane, lane_in, bc), ...);
     }
 
-    // The update row[j] -= l * c(j) needs entry j of the pivot column in every lane.  Two ways, used side by side so that
-    // neither the VALU (two v_readlane issues per value) nor the LDS pipe (shared by the waves of the CU) carries all
-    // of it: the first half of the columns takes the value from the owning lane's register through v_readlane, the
-    // second half reads it back from a 64-double LDS slot `bc` (any per-wave LDS area that is dead during the
-    // factorisation) that every lane has written its entry to.  The LDS reads are issued a group ahead.
     // USE_LDS = false keeps every broadcast on v_readlane (for kernels whose LDS pipe is the busier one).
     template <bool USE_LDS = true>
     __device__ __forceinline__ void factor(int lane_in, ldouble *bc)
