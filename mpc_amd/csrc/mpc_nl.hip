@@ -271,7 +271,19 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 double v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
                 for (int k = 1; k <= N; k++) {
-                    const double *st = &s_stage[(k - 1) * NL_STAGE_W];
+                    const double *stl = &s_stage[(k - 1) * NL_STAGE_W];
+                    double st[NL_STAGE_W];                // the stage record in one batch of LDS reads (otherwise the
+#pragma unroll                                             // scheduler waits for each value where it is used)
+                    for (int q = 0; q < NL_STAGE_W; q++) st[q] = (q < 30 || q >= 35) ? stl[q] : 0.0;
+                    double errk[7];                       // x_k - reference of stage k, read in the same batch
+#pragma unroll
+                    for (int c = 0; c < 7; c++) errk[c] = s_x[k * 7 + c];
+                    double refk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) refk[c] = s_ref[c * (N + 1) + k];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) errk[c] -= refk[c];
                     {
                         double n[6];
 #pragma unroll
@@ -298,12 +310,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                     double wv[7];
 #pragma unroll
                     for (int c = 0; c < 7; c++) wv[c] = (k < N ? wq[c] : wN[c]) * v[c];
-                    const double *xk = &s_x[k * 7];
 #pragma unroll
-                    for (int c = 0; c < 7; c++) {
-                        const double err = (c < 4) ? xk[c] - s_ref[c * (N + 1) + k] : xk[c];
-                        g = fma(wv[c], err, g);
-                    }
+                    for (int c = 0; c < 7; c++) g = fma(wv[c], errk[c], g);
                     if (valid) {
 #pragma unroll
                         for (int c = 0; c < 7; c++) s_wv[c * N + lane] = wv[c];
