@@ -20,7 +20,6 @@ for name, idx in (("heaviest", heavy[:1]), ("lightest", light[:1]), ("heaviest 1
     s2 = SkidpadBatch(50, 0.5, st[idx], model="L", device=dev)
     s2.run(50); torch.cuda.synchronize()
     t0 = time.perf_counter(); s2.run(1000); torch.cuda.synchronize(); t1 = time.perf_counter()
-    s2b = SkidpadBatch(50, 0.5, st[idx], model="L", device=dev)      # second time: ordered by the work of run 1 is not possible (state moved on), so time an identical fresh batch with the handle's order primed by a 50-step run
 
     i2 = s2.iters.cpu().numpy()
     print(f"{name:30s} B={len(idx):5d}  1000 steps {1e3*(t1-t0):7.2f} ms   iters mean {i2.mean():.0f} max {i2.max()}")
