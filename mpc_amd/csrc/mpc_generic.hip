@@ -223,6 +223,47 @@ __device__ __forceinline__ Vec<R> lds_solve(const double *M, const double *s_din
     return w;
 }
 
+// One stage of the Hessian accumulation: M(i,j) += sum_c wv_c(j) * v_c(i) for j <= i < k, over NC components whose
+// weighted columns start at s_wv + off[c].  Four columns per trip: their reads are issued together, then the updates,
+// then the writes.  The columns j >= k of s_wv are zero (their lanes have not started), so everything is read and
+// accumulated unconditionally; only the writes are guarded.  An unused slot (off = 0 with a zero v) adds exact zeros.
+template <int R, int NC>
+__device__ __forceinline__ void condense_columns(double *M, const double *s_wv, const int (&off)[NC], const double (&v)[R][NC],
+                                                 int k, int N, int lane)
+{
+    constexpr int CW = 4;
+#pragma unroll 1
+    for (int j0 = 0; j0 < k; j0 += CW) {
+        double wj[CW][NC], acc[CW][R];
+#pragma unroll
+        for (int u = 0; u < CW; u++) {
+            const int j = min(j0 + u, N - 1);
+#pragma unroll
+            for (int c = 0; c < NC; c++) wj[u][c] = s_wv[off[c] + j];
+#pragma unroll
+            for (int q = 0; q < R; q++) acc[u][q] = M[colp(j, N) + min(lane + WAVE * q, N - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CW; u++) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc[u][q] = fma(wj[u][c], v[q][c], acc[u][q]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CW; u++) {
+            const int j = j0 + u;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = lane + WAVE * q;
+                if (j < k && i >= j && i < k) M[colp(j, N) + i] = acc[u][q];
+            }
+        }
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveArgs a)
 {
@@ -248,6 +289,19 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
     for (int c = 0; c < 6; c++) wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);
     const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
+    // components of the weighted prediction columns that can be non-zero: stage weights are diagonal, the terminal
+    // weight is a full matrix (its column c matters)
+    unsigned nz_stage = 0, nz_term = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        if (wq[c] != 0.0) nz_stage |= 1u << c;
+        bool any = false;
+        for (int d = 0; d < 6; d++) any = any || (a.cost_scen ? a.cost_scen[43 * (size_t)s + 7 + d * 6 + c] : cfg.We[d * 6 + c]) != 0.0;
+        if (any) nz_term |= 1u << c;
+    }
+    nz_stage = __builtin_amdgcn_readfirstlane(nz_stage); nz_term = __builtin_amdgcn_readfirstlane(nz_term);
+    const int n_stage = __popc(nz_stage), n_term = __popc(nz_term);
+    auto nsel_k = [&](bool terminal) { return terminal ? n_term : n_stage; };
     bool valid[R], validd[R];
 #pragma unroll
     for (int q = 0; q < R; q++) { valid[q] = lane + WAVE * q < N; validd[q] = lane + WAVE * q < N - 1; }
@@ -396,40 +450,32 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                     }
                 }
                 wave_sync();
-                // M(i,j) += (W v_j)' v_i for j <= i < k (entries with i or j >= k are still zero)
-                // Four columns per trip: their reads are issued together, then the updates, then the writes.  A weighted
-                // column entry is exactly zero where the weight is, and the columns j >= k of s_wv are zero (their lanes
-                // have not started), so everything is read and accumulated unconditionally; only the writes are guarded.
-                constexpr int CW = 4;
-#pragma unroll 1
-                for (int j0 = 0; j0 < k; j0 += CW) {
-                    double wj[CW][6], acc[CW][R];
+                // M(i,j) += (W v_j)' v_i for j <= i < k (entries with i or j >= k are still zero).  Only the components
+                // with a non-zero weight contribute; when there are at most three of them (e.g. the LPV controller's
+                // weights on y, psi and delta) they are gathered into the first three slots and the short loop runs.
+                if (nsel_k(k == N) <= 3) {
+                    const unsigned nz = (k == N) ? nz_term : nz_stage;
+                    int off[3] = {0, 0, 0};
+                    double vs[R][3];
 #pragma unroll
-                    for (int u = 0; u < CW; u++) {
-                        const int j = min(j0 + u, N - 1);
+                    for (int q = 0; q < R; q++) { vs[q][0] = 0.0; vs[q][1] = 0.0; vs[q][2] = 0.0; }
+                    int t = 0;
 #pragma unroll
-                        for (int c = 0; c < 6; c++) wj[u][c] = s_wv[c * N + j];
+                    for (int c = 0; c < 6; c++) {
+                        const bool on = (nz >> c) & 1u;                  // wave-uniform
 #pragma unroll
-                        for (int q = 0; q < R; q++) acc[u][q] = M[colp(j, N) + min(lane + WAVE * q, N - 1)];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int slot = 0; slot < 3; slot++) {
+                            const bool here = on && t == slot;
+                            off[slot] = here ? c * N : off[slot];
 #pragma unroll
-                    for (int u = 0; u < CW; u++) {
-#pragma unroll
-                        for (int q = 0; q < R; q++) {
-#pragma unroll
-                            for (int c = 0; c < 6; c++) acc[u][q] = fma(wj[u][c], v[q][c], acc[u][q]);
+                            for (int q = 0; q < R; q++) vs[q][slot] = here ? v[q][c] : vs[q][slot];
                         }
+                        t += on ? 1 : 0;
                     }
-#pragma unroll
-                    for (int u = 0; u < CW; u++) {
-                        const int j = j0 + u;
-#pragma unroll
-                        for (int q = 0; q < R; q++) {
-                            const int i = lane + WAVE * q;
-                            if (j < k && i >= j && i < k) M[colp(j, N) + i] = acc[u][q];
-                        }
-                    }
+                    condense_columns<R, 3>(M, s_wv, off, vs, k, N, lane);
+                } else {
+                    const int off[6] = {0, N, 2 * N, 3 * N, 4 * N, 5 * N};
+                    condense_columns<R, 6>(M, s_wv, off, v, k, N, lane);
                 }
                 wave_sync();
             }
