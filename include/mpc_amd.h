@@ -192,6 +192,14 @@ int mpc_plan_skidpad_profile(void *stream, int B, int N, double dt, const double
 int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const double *traj, int ncol, int col,
                               const double *t, double scale, double *steer_out);
 
+/* check_control_amissible_invariance (stability.py:155-189) for nc level values c [nc] (device): the box around the
+ * ellipsoid x' P x <= c in the eigenbasis of P (eigenvectors Q [d][d] as columns, eigenvalues eig [d]; host arrays, as
+ * numpy.linalg.eigh returns them) has 2^d vertices (d <= 6); each is mapped through the closed loop
+ * x+ = A x + B sat(-K x, +-umax) (A [d][d], B [d], K [d] host arrays; umax = HUGE_VAL for the unsaturated law), and
+ * ok_out [nc] (device) receives 1 where no image leaves the box, else 0. */
+int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, const double *eig_host, const double *A_host,
+                         const double *B_host, const double *K_host, double umax, const double *c, int *ok_out);
+
 /* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
  * copied to a host array of 16 doubles after synchronising the stream:
  *   [0] scenarios, [1] sum iterations, [2] count status != 0, [3] count constrained solves,

@@ -392,6 +392,17 @@ int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const doubl
     return MPC_OK;
 }
 
+int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, const double *eig_host, const double *A_host,
+                         const double *B_host, const double *K_host, double umax, const double *c, int *ok_out)
+{
+    if (nc < 1 || d < 1 || d > 6 || !Q_host || !eig_host || !A_host || !B_host || !K_host || !(umax > 0.0) || !c || !ok_out)
+        return fail(nullptr, MPC_EINVAL, "mpc_invariance_check: bad argument (1 <= d <= 6, umax > 0)");
+    for (int i = 0; i < d; i++)
+        if (!(eig_host[i] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_invariance_check: P must be positive definite");
+    AUX_TRY(mpc::launch_invariance((hipStream_t)stream, nc, d, Q_host, eig_host, A_host, B_host, K_host, umax, c, ok_out));
+    return MPC_OK;
+}
+
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out)
 {

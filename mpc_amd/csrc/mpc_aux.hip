@@ -451,6 +451,57 @@ hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shif
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------- invariance
+// stability.py:155-189 (check_control_amissible_invariance) for a batch of level values c: the ellipsoid x' P x <= c is
+// boxed in the eigenbasis of P (bounds sqrt(c / eig_i)); every vertex of that box is mapped through the closed loop
+// x+ = A x + B sat(-K x, umax) and back into the eigenbasis, and the level passes when no image leaves the box.
+// One wavefront per level, one lane per vertex (d <= 6).  Q holds the eigenvectors as columns (numpy.linalg.eigh).
+struct InvArgs { double Q[36], eig[6], A[36], B[6], K[6]; double umax; int d; };
+
+__global__ __launch_bounds__(WAVE) void k_invariance(InvArgs p, int nc, const double *c, int *ok_out)
+{
+    const int lane = threadIdx.x, d = p.d;
+    const int ci = blockIdx.x;
+    if (ci >= nc) return;
+    const double cv = c[ci];
+    bool bad = false;
+    if (lane < (1 << d)) {
+        double bnd[6], vtx[6], x[6], xn[6];
+        for (int i = 0; i < d; i++) { bnd[i] = sqrt(cv / p.eig[i]); vtx[i] = ((lane >> i) & 1) ? bnd[i] : -bnd[i]; }
+        double u = 0.0;
+        for (int i = 0; i < d; i++) {
+            double acc = 0.0;
+            for (int j = 0; j < d; j++) acc += p.Q[i * d + j] * vtx[j];          // x = Q v
+            x[i] = acc;
+        }
+        for (int j = 0; j < d; j++) u -= p.K[j] * x[j];
+        u = fmin(fmax(u, -p.umax), p.umax);
+        for (int i = 0; i < d; i++) {
+            double acc = p.B[i] * u;
+            for (int j = 0; j < d; j++) acc += p.A[i * d + j] * x[j];
+            xn[i] = acc;
+        }
+        for (int i = 0; i < d; i++) {
+            double acc = 0.0;
+            for (int j = 0; j < d; j++) acc += p.Q[j * d + i] * xn[j];           // v+ = Q' x+
+            bad = bad || (fabs(acc) > bnd[i]);
+        }
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) ok_out[ci] = any_bad ? 0 : 1;
+}
+
+hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, const double *eig, const double *A,
+                             const double *B, const double *K, double umax, const double *c, int *ok_out)
+{
+    InvArgs p;
+    for (int i = 0; i < d * d; i++) { p.Q[i] = Q[i]; p.A[i] = A[i]; }
+    for (int i = 0; i < d; i++) { p.eig[i] = eig[i]; p.B[i] = B[i]; p.K[i] = K[i]; }
+    p.umax = umax; p.d = d;
+    hipLaunchKernelGGL(k_invariance, dim3(nc), dim3(WAVE), 0, st, p, nc, c, ok_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ statistics
 // Single-block reduction of the per-scenario solver records into 16 doubles (sums and maxima).
 __global__ __launch_bounds__(256) void k_stats(int B, const double *stat, const int *iters, const int *status,

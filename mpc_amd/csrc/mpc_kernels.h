@@ -106,6 +106,8 @@ hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const d
 hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const double *traj, int ncol, int col,
                                  const double *t, double scale, double *out);
 hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shift, int *order);
+hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, const double *eig, const double *A,
+                             const double *B, const double *K, double umax, const double *c, int *ok_out);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
                         double *out16);
 

@@ -316,3 +316,46 @@ def kkt_residuals(H, g, A, lo, up, U, lam):
     prim = max((v - up).max(), (lo - v).max(), 0.0)
     comp = np.abs(np.where(lam > 0, lam * (up - v), lam * (v - lo))).max()
     return stat, prim, comp
+
+
+# ---------------------------------------------------------------------------
+# stability.py restated (numpy).  Parity unpinned: the reference holds no fixture for these functions and cvxpy / ECOS,
+# which its LP loop needs, are absent; the vertex test and the bisection below are deterministic linear algebra.
+# ---------------------------------------------------------------------------
+def invariance_check(P, f, c) -> bool:
+    """stability.py:155-189: box around x'Px <= c in the eigenbasis of P, every vertex mapped through f and back."""
+    eigvals, Q = np.linalg.eigh(P)
+    bounds = np.sqrt(c / eigvals)
+    vertices = np.array(np.meshgrid(*[[-b, b] for b in bounds])).T.reshape(-1, len(bounds))
+    for vertex in vertices:
+        vertex_next = Q.T @ f(Q @ vertex)
+        if np.any(np.abs(vertex_next) > bounds):
+            return False
+    return True
+
+
+def invariance_binary_search(P, f, c_u, epsilon=1e-1):
+    """stability.py:192-211."""
+    c_l, c_best = 0, 0
+    if invariance_check(P, f, c_u):
+        return c_u
+    while c_u - c_l > epsilon:
+        c = (c_l + c_u) / 2
+        if invariance_check(P, f, c):
+            c_best = c; c_l = c
+        else:
+            c_u = c
+    return c_best
+
+
+def reconstruct_invariant_set(n, K, A, B, ubx, ubu):
+    """stability.py:93-109 without the plot and the file."""
+    phi = A - B @ K
+    F = np.concatenate((np.diag(1 / ubx), np.diag(-1 / ubx), np.zeros((2 * len(ubu), len(ubx)))), axis=0)
+    G = np.concatenate((np.zeros((2 * len(ubx), len(ubu))), np.diag(1 / ubu), np.diag(-1 / ubu)), axis=0)
+    C_initial = F + G @ K
+    C = C_initial
+    for _ in range(n):
+        C_initial = C_initial @ phi
+        C = np.concatenate((C, C_initial), axis=0)
+    return C

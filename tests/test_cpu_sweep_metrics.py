@@ -52,3 +52,27 @@ def test_sweep_points_and_grids():
     assert read_parameters("parameters_L.yaml")["controller"]["r"] != 3.0               # the packaged file is not touched
     ref = sweeps.step_reference(np.array([[-4.0, 0, 1, 0, 15, 0, 0, 0], [0.5, 0, 1, 0, 15, 0, 0, 0], [1, 0, 1, 0, 15, 0, 0, 0]]), -5.0)
     np.testing.assert_array_equal(ref[:, 0], [-5.0, -4.0, 0.5]); np.testing.assert_array_equal(ref[:, 1], [0, 0, 1])
+
+
+def test_reconstructed_invariant_set_rows():
+    """reconstruct_control_amissible_invariant_set (stability.py:93-109): host arithmetic, equal to the restatement, and
+    its rows are the constraints |phi^k x| <= ubx, |K phi^k x| <= ubu written as C x <= 1."""
+    import numpy as np
+    from oracle import oracle as O
+    from mpc_amd.stability import reconstruct_control_amissible_invariant_set
+    rng = np.random.default_rng(2)
+    A = np.eye(5) + 0.05 * rng.normal(size=(5, 5)); B = rng.normal(size=(5, 1)); K = rng.normal(size=(1, 5)) * 0.3
+    ubx = np.array([100, 100, 100, 100, 0.3]); ubu = np.array([0.9])
+    n = 6
+    C = reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu)
+    np.testing.assert_array_equal(C, O.reconstruct_invariant_set(n, K, A, B, ubx, ubu))
+    assert C.shape == (12 * (n + 1), 5)
+    phi = A - B @ K
+    x = rng.normal(size=5) * 0.05
+    for k in range(n + 1):
+        xk = np.linalg.matrix_power(phi, k) @ x
+        blk = C[12 * k: 12 * (k + 1)] @ x
+        # one 12-row block per k: rows 0-4 / 5-9 carry x_k / ubx (both signs), rows 10 / 11 carry K x_k / ubu (both signs)
+        np.testing.assert_allclose(blk[10], (K @ xk)[0] / ubu[0], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(blk[11], -(K @ xk)[0] / ubu[0], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(blk[:5], xk / ubx, rtol=1e-12, atol=1e-14)

@@ -397,6 +397,47 @@ def test_control_buffer_interp_matches_numpy():
         np.testing.assert_allclose(got0, [np.interp(0.013, nodes, traj[b, :, 2]) for b in range(B)], rtol=1e-13, atol=1e-14)
 
 
+def test_invariance_check_and_bisection(golden):
+    """stability.py's vertex test and bisection on the GPU (a batch of levels per launch) against the numpy restatement,
+    on the reference's printed (A, B) of terminal_set.m with the DARE gain; saturated and linear closed loops."""
+    import scipy.linalg
+    from oracle import oracle as O
+    from mpc_amd.stability import (ClosedLoopMap, binary_search, check_control_amissible_invariance,
+                                   check_invariance_batched)
+    g = golden["kat_terminal_set"]
+    A = np.asarray(g["A"], dtype=np.float64); B = np.asarray(g["B"], dtype=np.float64).reshape(5, 1)
+    Qw = np.diag([1e5, 1.0, 1e-3, 1e-3, 1.0]); R = np.array([[10.0]])
+    P = scipy.linalg.solve_discrete_are(A, B, Qw, R)
+    K = np.linalg.solve(B.T @ P @ B + R, B.T @ P @ A)
+    seen = set()
+    for umax in (0.9, np.inf, 0.05):
+        f = ClosedLoopMap(A, B, K, umax)
+        fref = lambda x, u=umax: A @ x + B[:, 0] * np.clip(-(K @ x)[0], -u, u)
+        cs = np.concatenate([np.logspace(-6, 6, 61), [1e-12, 1e9]])
+        ok = check_invariance_batched(P, f, cs)
+        ref = np.array([O.invariance_check(P, fref, c) for c in cs])
+        np.testing.assert_array_equal(ok, ref)
+        seen |= set(ok.tolist())
+        assert check_control_amissible_invariance(P, f, cs[7]) == ref[7]
+        for c_u, eps in ((1e4, 1e-1), (50.0, 1e-2), (0.05, 1e-1)):
+            assert binary_search(P, f, c_u, eps) == O.invariance_binary_search(P, fref, c_u, eps)
+    # a contraction passes at every level (the printed system above never does: the box is an outer approximation), and a
+    # saturated loop around an unstable plant passes only while the input stays unsaturated
+    Au = np.diag([1.05, 0.9, 0.8, 0.7, 0.6]); Bu = np.array([[1.0], [0.0], [0.0], [0.0], [0.0]]); Ku = np.array([[0.6, 0, 0, 0, 0.0]])
+    Pu = np.diag([1.0, 2.0, 3.0, 4.0, 5.0])
+    for (Ax, Bx, Kx, ux) in ((0.5 * np.eye(5), B, np.zeros((1, 5)), np.inf), (Au, Bu, Ku, 0.5)):
+        f = ClosedLoopMap(Ax, Bx, Kx, ux)
+        fref = lambda x, A_=Ax, B_=Bx, K_=Kx, u=ux: A_ @ x + B_[:, 0] * np.clip(-(K_ @ x)[0], -u, u)
+        cs = np.logspace(-4, 4, 41)
+        ok = check_invariance_batched(Pu, f, cs)
+        np.testing.assert_array_equal(ok, [O.invariance_check(Pu, fref, c) for c in cs])
+        seen |= set(ok.tolist())
+        assert binary_search(Pu, f, 1e4, 1e-1) == O.invariance_binary_search(Pu, fref, 1e4, 1e-1)
+    assert seen == {True, False}
+    with pytest.raises(TypeError):
+        check_control_amissible_invariance(P, lambda x: x, 1.0)
+
+
 def test_library_error_paths():
     """Argument checks of the C ABI: unsupported horizon, oversize batch, missing buffers raise with a message."""
     from mpc_amd.controllers import LOcp
