@@ -165,8 +165,9 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         const gdouble *w = (const gdouble *)prm.warm;
         double u0 = w[lc], a0 = w[WAVE + lc], a1 = w[2 * WAVE + lc], a2 = w[3 * WAVE + lc], a3 = w[4 * WAVE + lc];
         if (prm.warm_mode == 2) {
-            const double un = __shfl_down(u0, 1), b0 = __shfl_down(a0, 1), b1 = __shfl_down(a1, 1);
-            const double b2 = __shfl_down(a2, 1), b3 = __shfl_down(a3, 1);
+            // the record of the next stage, straight from memory (no cross-lane shuffle of loaded values)
+            const int ln = min(lc + 1, N - 1);
+            const double un = w[ln], b0 = w[WAVE + ln], b1 = w[2 * WAVE + ln], b2 = w[3 * WAVE + ln], b3 = w[4 * WAVE + ln];
             if (lane < N - 1) { u0 = un; a0 = b0; a1 = b1; }
             if (lane < N - 2) { a2 = b2; a3 = b3; }
         }

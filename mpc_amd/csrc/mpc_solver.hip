@@ -352,7 +352,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
 #pragma unroll 1
             for (int k = 0; k < N; k++) {
                 const double *st = &s_stage[k * STAGE_W];
-                const double uk = __shfl(U, k);
+                const double uk = bcast(U, k);                 // k is wave-uniform: a v_readlane pair, no LDS round trip
                 const double n0 = x[0] + st[0] * x[2] + st[1] * x[3] + st[8];
                 const double n1 = x[1] + st[2] * x[2] + st[3] * x[3] + st[9];
                 const double n2 = x[2] + dt * x[4];
