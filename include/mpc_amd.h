@@ -63,6 +63,8 @@ typedef struct mpc_config {
     int sqp_max_iter;    /* SQP iteration cap per solve (status 1 when reached)               */
     int ipm_cold_start;  /* 0 (default): closed-loop steps, and the SQP iterations of one NL solve, start the interior
                           * point from the previous solve when that one hit a bound too; 1: always cold start */
+    double step_ramp_length; /* MPC_PLANNER_STEP loops: progress over which the step reference rises (StepPlanner's
+                              * ramp_length, utils/step_planning.py:51,75-79); 0 = the pure step the simulators use */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
@@ -171,11 +173,12 @@ int mpc_lsim_run(void *stream, int B, int nsteps, double dt, const double *mp6_h
 
 /* SkidpadPlanner.request_waypoints (utils/path_planning.py:220-261, constant-speed branch whatever the lap) and
  * StepPlanner.request_waypoints (utils/step_planning.py:88-117): pose [B][3] = x, y, heading;
- * wp_out [B][N+1][4]; progress_out [B]; abs_out [B][N+1][4] (step planner, may be NULL). */
+ * wp_out [B][N+1][4]; progress_out [B]; abs_out [B][N+1][4] (step planner, may be NULL); ramp_length >= 0 is the
+ * StepPlanner attribute of that name (step_planning.py:51,75-79), 0 for the pure step. */
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out);
-int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, const double *target_vel, double *wp_out,
-                  double *progress_out, double *abs_out);
+int mpc_plan_step(void *stream, int B, int N, double dt, double ramp_length, const double *pose, const double *target_vel,
+                  double *wp_out, double *progress_out, double *abs_out);
 /* SkidpadPlanner.request_waypoints with its speed profile (utils/path_planning.py:220-261 incl. the branch for laps
  * outside 0..7, :241-248, and progress2speed, :93-126): as mpc_plan_skidpad, plus zones [B][7] = accel_zone_1_start,
  * accel_zone_1_end, braking_zone_1_start, braking_zone_1_end, braking_zone_2_start, braking_zone_2_end,

@@ -21,7 +21,7 @@ class MpcConfig(C.Structure):
         ("w", C.c_double * 7), ("We", C.c_double * 36), ("eps", C.c_double), ("tol_mu", C.c_double),
         ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
         ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
-        ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int),
+        ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int), ("step_ramp_length", C.c_double),
     ]
 
 
@@ -48,7 +48,7 @@ _SIGS = {
     "mpc_lsim_run": ([_vp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_plan_skidpad": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_plan_skidpad_profile": ([_vp, C.c_int, C.c_int, C.c_double] + [_vp] * 8, C.c_int),
-    "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_control_buffer_interp": ([_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_double, _vp], C.c_int),
     "mpc_invariance_check": ([_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _vp, _vp], C.c_int),
     "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),

@@ -77,7 +77,7 @@ class _CondensedMpc:
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
-                 ipm_warm_start: bool = True, _host_only: bool = False):
+                 ipm_warm_start: bool = True, step_ramp_length: float = 0.0, _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
@@ -100,6 +100,9 @@ class _CondensedMpc:
         self.batch = int(batch)
         self._tol = (tol_mu, tol_res, max_iter)
         self._ipm_cold = 0 if ipm_warm_start else 1
+        # the step-reference closed loops generate their waypoints on the GPU: StepPlanner's ramp_length travels with
+        # the controller definition (utils/step_planning.py:51)
+        self._step_ramp = float(step_ramp_length)
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
             self.device = None
             self.solver = None
@@ -159,6 +162,7 @@ class _CondensedMpc:
         cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
         cfg.lpv_lin_prev = 0
         cfg.ipm_cold_start = self._ipm_cold
+        cfg.step_ramp_length = self._step_ramp
         return cfg
 
     def stability(self):
@@ -388,6 +392,7 @@ class NLOcp(_CondensedMpc):
         cfg.tol_mu, cfg.tol_res, cfg.max_iter = self._tol
         cfg.sqp_tol, cfg.sqp_max_iter = self._sqp
         cfg.ipm_cold_start = self._ipm_cold
+        cfg.step_ramp_length = self._step_ramp
         return cfg
 
     def stability(self):

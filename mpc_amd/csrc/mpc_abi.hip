@@ -62,6 +62,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
         return fail(nullptr, MPC_EINVAL, b);
     }
     if (cfg->B < 1 || !(cfg->dt > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: need B >= 1 and dt > 0");
+    if (!(cfg->step_ramp_length >= 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: step_ramp_length must be >= 0");
     if (cfg->kind == MPC_KIND_NL) {
         if (!mpc::horizon_templated(cfg->N)) return fail(nullptr, MPC_EINVAL, "mpc_create: the NL controller needs a horizon of 10, 20, 30, 40, 50 or 64");
         if (!(cfg->w_nl[7] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight w_nl[7] must be positive (strict convexity)");
@@ -267,7 +268,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     mpc::SolveArgs a = {};
     a.mode = planner == MPC_PLANNER_SKIDPAD ? mpc::MODE_SKIDPAD : mpc::MODE_STEP; a.B = B;
     a.nsteps = nsteps; a.u_hist = u_hist; a.x_hist = x_hist; a.nx_plant = 8;
-    a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel;
+    a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel; a.step_ramp = h->cfg.step_ramp_length;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
@@ -289,7 +290,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
         return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: missing argument");
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_OFL; a.B = B; a.nsteps = nsteps; a.nx_plant = 10;
-    a.state = state10; a.target_vel = target_vel; a.ekf_x = ekf_x; a.ekf_P = ekf_P; a.meas_noise = meas_noise;
+    a.state = state10; a.target_vel = target_vel; a.step_ramp = h->cfg.step_ramp_length; a.ekf_x = ekf_x; a.ekf_P = ekf_P; a.meas_noise = meas_noise;
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
@@ -423,11 +424,12 @@ int mpc_plan_skidpad_profile(void *stream, int B, int N, double dt, const double
     return MPC_OK;
 }
 
-int mpc_plan_step(void *stream, int B, int N, double dt, const double *pose, const double *target_vel, double *wp_out,
-                  double *progress_out, double *abs_out)
+int mpc_plan_step(void *stream, int B, int N, double dt, double ramp_length, const double *pose, const double *target_vel,
+                  double *wp_out, double *progress_out, double *abs_out)
 {
-    if (B < 1 || N < 1 || !pose || !target_vel || !wp_out) return fail(nullptr, MPC_EINVAL, "mpc_plan_step: bad argument");
-    AUX_TRY(mpc::launch_plan_step((hipStream_t)stream, B, N, dt, pose, target_vel, wp_out, progress_out, abs_out));
+    if (B < 1 || N < 1 || !(ramp_length >= 0.0) || !pose || !target_vel || !wp_out)
+        return fail(nullptr, MPC_EINVAL, "mpc_plan_step: bad argument");
+    AUX_TRY(mpc::launch_plan_step((hipStream_t)stream, B, N, dt, ramp_length, pose, target_vel, wp_out, progress_out, abs_out));
     return MPC_OK;
 }
 

@@ -302,7 +302,7 @@ hipError_t launch_lsim_run(hipStream_t st, int B, int nsteps, double dt, const d
 // slow-down factor) a skidpad request for a lap outside 0..7 follows the planner's speed profile instead of the
 // constant target speed (utils/path_planning.py:238-248): that recurrence is sequential, so lane 0 walks it and parks
 // the progresses in the x slot of wp_out, from where the lanes turn them into poses.
-__global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const double *pose, const int *lap,
+__global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, double ramp, const double *pose, const int *lap,
                                                double *prev_progress, const double *target_vel, const double *zones,
                                                double *wp_out, double *progress_out, double *abs_out, double *speeds_out)
 {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(int mode, int N, double dt, const
         double o[4];
         const double q = profile ? wps[4 * k] : waypoint_progress(p0, v, dt, k);
         if (mode == MODE_SKIDPAD) sk_pose(q, o);
-        else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+        else step_pose(q, ramp, o);
         if (abs_out) {
             double *w = abs_out + ((size_t)s * (N + 1) + k) * 4;
             w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
@@ -361,15 +361,15 @@ hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const do
                                double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
                                double *progress_out, double *speeds_out)
 {
-    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_SKIDPAD, N, dt, pose, lap, prev_progress,
+    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_SKIDPAD, N, dt, 0.0, pose, lap, prev_progress,
                        target_vel, zones, wp_out, progress_out, (double *)nullptr, speeds_out);
     return hipGetLastError();
 }
 
-hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
+hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, double ramp, const double *pose, const double *target_vel,
                             double *wp_out, double *progress_out, double *abs_out)
 {
-    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_STEP, N, dt, pose, (const int *)nullptr,
+    hipLaunchKernelGGL(k_plan, dim3(B), dim3(WAVE), 0, st, (int)MODE_STEP, N, dt, ramp, pose, (const int *)nullptr,
                        (double *)nullptr, target_vel, (const double *)nullptr, wp_out, progress_out, abs_out,
                        (double *)nullptr);
     return hipGetLastError();

@@ -228,6 +228,13 @@ __device__ __forceinline__ void sk_pose(double q, double *o)
     } else { o[0] = q; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
 }
 
+// utils/step_planning.py:63-80: a unit step in y at progress 0, reached over `ramp` metres of progress (ramp_length;
+// 0 = the pure step of the reference's simulators), heading along x.
+__device__ __forceinline__ void step_pose(double q, double ramp, double *o)
+{
+    o[0] = q; o[1] = (q < 0.0) ? 0.0 : (q < ramp) ? q / ramp : 1.0; o[2] = 1.0; o[3] = 0.0;
+}
+
 // cos and sin of atan2(hs, hc) without the angle: the heading vector normalised (skidpad_simulator.py:104 takes the
 // angle and path_planning.py:253-260 its cosine and sine again)
 __device__ __forceinline__ void unit_heading(double hc, double hs, double &ch, double &sh)

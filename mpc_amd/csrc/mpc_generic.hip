@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 double o[4];
                 const double q = (k == 0) ? p0 : p0 + cs[qi] * dt;
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
-                else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+                else step_pose(q, a.step_ramp, o);
                 to_car_frame(o, px, py, ch, sh);
                 s_ref[k] = o[0]; s_ref[(N + 1) + k] = o[1]; s_ref[2 * (N + 1) + k] = o[3];
                 s_p[k] = tvel;

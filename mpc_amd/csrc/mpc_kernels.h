@@ -38,6 +38,7 @@ struct SolveArgs {
     const double *x0, *wp, *p, *d_hat;                    // MODE_SOLVE inputs
     double *state; int *lap; double *prev_progress;       // closed-loop state (updated)
     const double *target_vel;
+    double step_ramp;                                     // MODE_STEP / MODE_OFL: ramp length of the step reference (0 = pure step)
     double *lin_x, *lin_u;                                // LPV linearisation memory (updated)
     const double *mp_scen;                                // optional per-scenario model parameters
     const double *cost_scen;                              // optional per-scenario cost [B][43]: diag W (7), then W_e (6x6)
@@ -95,7 +96,7 @@ hipError_t launch_ekf_jacobian(hipStream_t st, int B, double dt, const double *m
 hipError_t launch_plan_skidpad(hipStream_t st, int B, int N, double dt, const double *pose, const int *lap,
                                double *prev_progress, const double *target_vel, const double *zones, double *wp_out,
                                double *progress_out, double *speeds_out);
-hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, const double *pose, const double *target_vel,
+hipError_t launch_plan_step(hipStream_t st, int B, int N, double dt, double ramp, const double *pose, const double *target_vel,
                             double *wp_out, double *progress_out, double *abs_out);
 hipError_t launch_dlqr_run(hipStream_t st, int B, int nx, int nsteps, double dt, const double *mp6, const double *K5,
                            const double *K_scen, double rate_limit, double angle_limit, double *x, double *u_hist,

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 double o[4];
                 const double q = (k == 0) ? p0 : p0 + (k < WAVE ? cs0 : cs1) * dt;
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
-                else { o[0] = q; o[1] = (q < 0.0) ? 0.0 : 1.0; o[2] = 1.0; o[3] = 0.0; }
+                else step_pose(q, a.step_ramp, o);
                 to_car_frame(o, px, py, ch, sh);
 #pragma unroll
                 for (int c = 0; c < 4; c++) s_ref[c * (N + 1) + k] = o[c];

@@ -247,8 +247,9 @@ __device__ __forceinline__ void ekf_measurement_update_wave(int lane, double *xe
 }
 
 // warm: per-scenario record of IPM_WARM_DOUBLES doubles in global memory (inputs and the four multiplier vectors of the
-// last solve, [5][64], then a validity flag); warm_mode 0 = cold start, 1 = start from the record, 2 = start from the
-// record moved one stage ahead (the next closed-loop step).  The record is rewritten at exit whenever warm != nullptr.
+// last solve, [5][64], then a validity flag; the any-horizon kernel uses the same layout with rows of 128);
+// warm_mode 0 = cold start, 1 = start from the record, 2 = start from the record moved one stage ahead (the next
+// closed-loop step).  The record is rewritten at exit whenever warm != nullptr.
 struct IpmParams { double dt, umax, dmax, tol_mu, tol_res; int max_iter; double *warm; int warm_mode; };
 struct IpmResult { double U, mu, res; int iters, status; };
 

@@ -10,8 +10,8 @@ from .. import _dev, _lib
 class StepPlanner:
     def __init__(self, target_vel: float, Nt: float = 10, dt: float = 0.2, ramp_length: float = 0.0, fields=None,
                  device=None):
-        if ramp_length != 0.0:
-            raise NotImplementedError("only the pure step (ramp_length = 0) used by the reference's simulators is implemented")
+        if not ramp_length >= 0.0:
+            raise ValueError("ramp_length must be >= 0")
         self.target_vel = target_vel
         self.dt = dt
         self.Nt = Nt
@@ -33,8 +33,8 @@ class StepPlanner:
         wp = torch.empty((B, Nt + 1, 4), dtype=torch.float64, device=dev)
         ab = torch.empty((B, Nt + 1, 4), dtype=torch.float64, device=dev) if want_absolute else None
         prog = torch.empty((B,), dtype=torch.float64, device=dev)
-        rc = self._lib.mpc_plan_step(_dev.stream_ptr(dev), B, int(Nt), float(dt), _dev.ptr(pose), _dev.ptr(target_vel),
-                                     _dev.ptr(wp), _dev.ptr(prog), _dev.ptr(ab))
+        rc = self._lib.mpc_plan_step(_dev.stream_ptr(dev), B, int(Nt), float(dt), float(self.ramp_length),
+                                     _dev.ptr(pose), _dev.ptr(target_vel), _dev.ptr(wp), _dev.ptr(prog), _dev.ptr(ab))
         _lib.check(rc, None, "mpc_plan_step")
         return wp, prog, ab
 

@@ -180,6 +180,22 @@ def main():
     rec["ncases"] = np.array(len(cases))
     np.savez_compressed(os.path.join(OUT, "planner_speed_profile.npz"), **rec)
 
+    # ---- step planner with a ramped step (ramp_length > 0, step_planning.py:75-79) ----
+    rec = {}
+    rrng = np.random.default_rng(4242)
+    for ci, (v, N, dt, ramp) in enumerate(((15.0, 50, 0.01, 2.0), (8.0, 80, 0.0125, 5.5), (10.0, 30, 0.02, 0.75))):
+        spn = StepPlanner(target_vel=v, Nt=N, dt=dt, ramp_length=ramp)
+        poses, wps, absw, spds, p0s = [], [], [], [], []
+        for _ in range(24):
+            px, py, hd = rrng.uniform(-6, ramp + 2), rrng.uniform(-0.5, 1.5), rrng.uniform(-0.3, 0.3)
+            w, spd, p0, R, ab = spn.request_waypoints(px, py, hd)
+            poses.append([px, py, hd]); wps.append(w.copy()); absw.append(ab.copy()); spds.append(spd.copy()); p0s.append(p0)
+        rec.update({f"c{ci}_pose": np.array(poses), f"c{ci}_wp": np.array(wps), f"c{ci}_abs": np.array(absw),
+                    f"c{ci}_speeds": np.array(spds), f"c{ci}_p0": np.array(p0s), f"c{ci}_N": np.array(N),
+                    f"c{ci}_dt": np.array(dt), f"c{ci}_v": np.array(v), f"c{ci}_ramp": np.array(ramp)})
+    rec["ncases"] = np.array(3)
+    np.savez_compressed(os.path.join(OUT, "step_ramp.npz"), **rec)
+
     # ---- known answers held by the reference: terminal_set.m:4-10 (A 5x5, B at vx=15, dt=0.02), values as printed ----
     A = np.array([[1.0, 0.3, 0.02, 0.0, 0.0],
                   [0.0, 1.0, 0.0, 0.02, 0.0],

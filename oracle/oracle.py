@@ -58,7 +58,7 @@ class Oracle:
         L.orc_skidpad_waypoints_profile.restype = C.c_double
         L.orc_progress2speed.argtypes = [_dp, C.c_double, C.c_double]
         L.orc_progress2speed.restype = C.c_double
-        L.orc_step_waypoints.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, _dp, _dp, _dp]
+        L.orc_step_waypoints.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]
         L.orc_step_waypoints.restype = C.c_double
         L.orc_mpc_optimize.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                        C.c_double, C.c_int]
@@ -130,10 +130,10 @@ class Oracle:
     def progress2speed(self, zones, v, q):
         return self.lib.orc_progress2speed(_ptr(np.ascontiguousarray(zones, dtype=np.float64)), float(v), float(q))
 
-    def step_waypoints(self, x, y, heading, v, N, dt):
+    def step_waypoints(self, x, y, heading, v, N, dt, ramp_length=0.0):
         wp = np.zeros((N + 1, 4)); sp = np.zeros(N + 1); ab = np.zeros((N + 1, 4))
-        p0 = self.lib.orc_step_waypoints(float(x), float(y), float(heading), float(v), int(N), float(dt), _ptr(wp),
-                                         _ptr(sp), _ptr(ab))
+        p0 = self.lib.orc_step_waypoints(float(x), float(y), float(heading), float(v), int(N), float(dt),
+                                         float(ramp_length), _ptr(wp), _ptr(sp), _ptr(ab))
         return wp, sp, p0, ab
 
     # -- controllers ------------------------------------------------------

@@ -89,6 +89,64 @@ def test_planners_match_reference_vectors(golden):
         assert p0 == pose[0] and np.all(speeds == v)
 
 
+def test_step_planner_ramped_step(golden):
+    """StepPlanner(ramp_length > 0) (utils/step_planning.py:75-79), batched, against the reference's recorded outputs."""
+    import torch
+    from mpc_amd.utils.step_planning import StepPlanner
+    g = golden["step_ramp"]
+    for ci in range(int(g["ncases"])):
+        N, dt, v, ramp = int(g[f"c{ci}_N"]), float(g[f"c{ci}_dt"]), float(g[f"c{ci}_v"]), float(g[f"c{ci}_ramp"])
+        spn = StepPlanner(target_vel=v, Nt=N, dt=dt, ramp_length=ramp)
+        pose = torch.as_tensor(g[f"c{ci}_pose"], device=spn.device)
+        tv = torch.full((pose.shape[0],), v, dtype=torch.float64, device=spn.device)
+        wp, prog, ab = spn.request_waypoints_batched(pose, tv)
+        np.testing.assert_allclose(wp.cpu().numpy(), g[f"c{ci}_wp"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_array_equal(ab.cpu().numpy(), g[f"c{ci}_abs"])
+        np.testing.assert_array_equal(prog.cpu().numpy(), g[f"c{ci}_p0"])
+        w, speeds, p0, R, ab1 = spn.request_waypoints(*g[f"c{ci}_pose"][3])
+        np.testing.assert_allclose(w, g[f"c{ci}_wp"][3], rtol=1e-13, atol=1e-13)
+        np.testing.assert_array_equal(speeds, g[f"c{ci}_speeds"][3])
+    with pytest.raises(ValueError):
+        StepPlanner(target_vel=8.0, ramp_length=-1.0)
+
+
+@pytest.mark.parametrize("model,N,cache", [("L", 50, True), ("L", 50, False), ("LPV", 80, False), ("NL", 20, False)])
+def test_closed_loop_on_ramped_step_matches_checker(orc64, model, N, cache):
+    """The fused step-reference loop with StepPlanner's ramp_length (every kernel's planner stage) against the checker's
+    loop: plan on the ramp -> solve -> RK4 plant."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import StepBatch
+    ramp, nsteps, v = 3.0, 40, 8.0
+    dt = 0.01
+    Tf = dt * N
+    hd = np.arctan2(1.0, ramp)                                             # second scenario: already driving up the ramp
+    start = np.array([[-1.0, 0.0, 1.0, 0.0, v, 0.0, 0.0, 0.0], [0.9, 0.3, np.cos(hd), np.sin(hd), v, 0.0, 0.0, 0.0],
+                      [-4.5, -0.05, 1.0, 0.0, v, 0.05, 0.0, -0.02]])
+    kw = dict(sqp_tol=1e-10, sqp_max_iter=50) if model == "NL" else {}
+    a = StepBatch(N, Tf, start, model=model, fixed_model_cache=cache, step_ramp_length=ramp, **kw)
+    xs, us = a.run(nsteps, record=True)
+    plain = StepBatch(N, Tf, start, model=model, fixed_model_cache=cache, **kw)
+    xs0, us0 = plain.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    xs, us = xs.cpu().numpy(), us.cpu().numpy()
+    assert np.abs(us - us0.cpu().numpy()).max() > 1e-3                      # the ramp changes the response
+    cfg = O.make_cfg(model, N, Tf, **({"sqp_tol": 1e-11, "sqp_max_iter": 50} if model == "NL" else {}))
+    for b in range(start.shape[0]):
+        x = start[b].copy(); lx = np.zeros((6, N + 1)); lu = np.zeros(N); warm = None
+        for i in range(nsteps):
+            wp, sp, p0, ab = orc64.step_waypoints(x[0], x[1], np.arctan2(x[3], x[2]), v, N, dt, ramp)
+            if model == "NL":
+                st, traj, U, lam, info = orc64.nl_optimize(cfg, x[[0, 1, 2, 3, 5, 6, 7]], wp, sp, warm)
+                warm = U
+            else:
+                st, traj, U, lam, info = orc64.optimize(cfg, x[[0, 1, 2, 3, 5, 6, 7]], wp, sp, 0.0, lx, lu)
+            tol = 10 * 1e-5 * max(abs(U[0]), 1e-3 * 0.9)
+            assert abs(us[i, b] - U[0]) <= tol, (model, b, i, us[i, b], U[0])
+            x = orc64.plant_rk4(x, U[0], dt, cfg[3:9])
+            np.testing.assert_allclose(xs[i, b], x, rtol=0, atol=1e-7)
+
+
 def test_skidpad_planner_speed_profile(orc64, golden):
     """Laps outside 0..7: the speed profile of utils/path_planning.py:241-248 through the class surface and batched,
     against the reference's recorded outputs and the CPU restatement."""

@@ -129,6 +129,24 @@ def test_step_planner(orc64, golden):
         np.testing.assert_allclose(ab, ab_ref, rtol=1e-13, atol=1e-13)
 
 
+def test_step_planner_ramped_step(orc64, golden):
+    """StepPlanner(ramp_length > 0): the reference's simulators never set it, its planner supports it
+    (step_planning.py:75-79); outputs recorded from the reference's planner."""
+    g = golden["step_ramp"]
+    on_ramp = 0
+    for ci in range(int(g["ncases"])):
+        N, dt, v, ramp = int(g[f"c{ci}_N"]), float(g[f"c{ci}_dt"]), float(g[f"c{ci}_v"]), float(g[f"c{ci}_ramp"])
+        for pose, wp_ref, ab_ref, sp_ref, p0_ref in zip(g[f"c{ci}_pose"], g[f"c{ci}_wp"], g[f"c{ci}_abs"],
+                                                        g[f"c{ci}_speeds"], g[f"c{ci}_p0"]):
+            wp, sp, p0, ab = orc64.step_waypoints(pose[0], pose[1], pose[2], v, N, dt, ramp)
+            np.testing.assert_allclose(wp, wp_ref, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(ab, ab_ref, rtol=1e-13, atol=1e-13)
+            np.testing.assert_array_equal(sp, sp_ref)
+            assert p0 == p0_ref
+            on_ramp += int(np.sum((ab_ref[:, 1] > 0) & (ab_ref[:, 1] < 1)))
+    assert on_ramp > 100
+
+
 def test_linear_model_known_answer_terminal_set(orc64, golden):
     """terminal_set.m:4-10 prints the float32 forward-Euler (A,B) at vx=15, dt=0.02 without the px row."""
     g = golden["kat_terminal_set"]
