@@ -84,9 +84,22 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
     t0 = time.perf_counter()
     orc.skidpad_run(cfg, st, laps, pp, VX, nsteps, record=False)
     dtm = time.perf_counter() - t0
-    return {"value": nscen * nsteps / dtm, "unit": "scenario-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{nscen} scenarios x {nsteps} closed-loop steps ({kind} controller, N={N}, vx={VX}; transient "
-                      f"included), oracle/mpc_oracle.c double build, OpenMP over scenarios, {dtm:.1f} s"}
+    out = {"value": nscen * nsteps / dtm, "unit": "scenario-steps/s", "cores": threads, "kind": "port",
+           "sample": f"{nscen} scenarios x {nsteps} closed-loop steps ({kind} controller, N={N}, vx={VX}; transient "
+                     f"included), oracle/mpc_oracle.c double build, OpenMP over scenarios, {dtm:.1f} s"}
+    if workload == "c2":
+        # one scenario on one thread, a call per step: the latency a single controller sees on this host (the
+        # reference reports the median of its per-solve run times, plot_generator.py:1160-1191)
+        x = np.array([15.0, 0.1, 1.0, 0.0, VX, 0.0, 0.0, 0.0]); lap, prev = 0, 0.0          # skidpad_simulator.py:50-60
+        lat = []
+        for _ in range(1000):
+            t0 = time.perf_counter()
+            _, x, lap, prev, _, _ = orc.skidpad_step(cfg, x, lap, prev, VX)
+            lat.append(time.perf_counter() - t0)
+        out["single_scenario"] = {"p50_step_latency_ms": 1e3 * float(np.median(lat)), "p99_step_latency_ms":
+                                  1e3 * float(np.percentile(lat, 99)), "cores": 1,
+                                  "sample": "default skidpad start, 1000 closed-loop steps, one call per step"}
+    return out
 
 
 def measured_traffic(args):
