@@ -24,7 +24,7 @@ def _tol(u_ref, umax=0.9):
 # (one and two stages per lane, and its largest size)
 @pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("L", 10, 0.5), ("OFL", 50, 0.5), ("L", 64, 0.64),
                                        ("L", 54, 0.54), ("OFL", 80, 0.8), ("L", 100, 1.0), ("L", 128, 1.28),
-                                       ("L", 7, 0.07)])
+                                       ("L", 7, 0.07), ("L", 2, 0.02), ("OFL", 3, 0.03)])
 def test_solve_only_matches_checker(orc80, kind, N, Tf):
     import torch
     from oracle import oracle as O
