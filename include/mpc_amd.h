@@ -9,6 +9,11 @@
  * negative MPC_E* code; mpc_last_error() gives the text.  No exceptions cross this boundary and the
  * library owns nothing but the handle and its workspace.
  *
+ * Devices: a handle belongs to mpc_config.device.  Entry points that take a handle make that device
+ * current while they run and give the caller's current device back on return; the stream and the
+ * buffers passed must live on the handle's device.  Entry points without a handle run on the calling
+ * thread's current device.
+ *
  * The reference has no FFI of its own for this path: its controllers hand the problem to
  * acados_template's ctypes binding (AcadosOcpSolver.cost_set/set/solve_for_x0/get, LMPC2.py:301-329,
  * LPVMPC.py:260-312, OFLMPC2.py:320-349).  The entry points below are what that binding is

@@ -47,6 +47,28 @@ static int hip_fail(mpc_handle *h, hipError_t e, const char *what)
         if (e_ != hipSuccess) return hip_fail(h, e_, #call);    \
     } while (0)
 
+// Makes a handle's device current for the duration of an entry point and gives the caller's device back afterwards.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+#define ON_HANDLE_DEVICE(h)                                                       \
+    DeviceScope dev_scope_((h)->cfg.device);                                      \
+    if (dev_scope_.err != hipSuccess) return hip_fail(h, dev_scope_.err, "selecting the handle's device")
+
 extern "C" {
 
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -77,7 +99,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);
     memcpy(d.w_nl, cfg->w_nl, sizeof d.w_nl); memcpy(d.we_nl, cfg->we_nl, sizeof d.we_nl);
     d.eps_nl = cfg->eps_nl; d.sqp_tol = cfg->sqp_tol > 0 ? cfg->sqp_tol : 1e-9; d.sqp_max_iter = cfg->sqp_max_iter > 0 ? cfg->sqp_max_iter : 30;
-    hipError_t e = hipSetDevice(cfg->device);
+    DeviceScope scope(cfg->device);
+    hipError_t e = scope.err;
     const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
     if (e == hipSuccess) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
@@ -104,6 +127,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
 void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
+    DeviceScope scope(h->cfg.device);
     (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
@@ -114,6 +138,7 @@ void mpc_destroy(mpc_handle *h)
 int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
 {
     if (!h) return MPC_EINVAL;
+    ON_HANDLE_DEVICE(h);
     if (!mp_per_scenario) { (void)hipFree(h->mp_scen); h->mp_scen = nullptr; return MPC_OK; }
     const size_t bytes = (size_t)h->cfg.B * 6 * sizeof(double);
     if (!h->mp_scen) HIP_TRY(h, hipMalloc(&h->mp_scen, bytes));
@@ -124,6 +149,7 @@ int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario)
 int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario)
 {
     if (!h) return MPC_EINVAL;
+    ON_HANDLE_DEVICE(h);
     if (h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_set_cost_weights: the NL controller's weights are fixed by its definition");
     if (!cost_per_scenario) { (void)hipFree(h->cost_scen); h->cost_scen = nullptr; return MPC_OK; }
     const size_t bytes = (size_t)h->cfg.B * 43 * sizeof(double);
@@ -135,6 +161,7 @@ int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario)
 int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
 {
     if (!h) return MPC_EINVAL;
+    ON_HANDLE_DEVICE(h);
     if (h->cfg.kind == MPC_KIND_LPV || h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV and NL models are re-linearised every step");
     if (!(vx == vx)) { h->sh_on = false; return MPC_OK; }   // NaN switches the cache off
     // the cache belongs to the register-resident kernels; other horizons keep condensing per scenario (same results)
@@ -224,6 +251,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
                    int *status_out, int *iters_out)
 {
     if (int rc = check_batch(h, B, "mpc_solve_only")) return rc;
+    ON_HANDLE_DEVICE(h);
     if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_solve_only: x0, wp, p and U_out are required");
     if (h->cfg.kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_solve_only: LPV needs lin_x and lin_u");
     if (h->cfg.kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_solve_only: NL needs lin_u (the SQP iterate)");
@@ -258,6 +286,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
                         double *x_hist, int *status_out, int *iters_out)
 {
     if (int rc = check_batch(h, B, "mpc_closed_loop_step")) return rc;
+    ON_HANDLE_DEVICE(h);
     if (nsteps < 1) return fail(h, MPC_EINVAL, "mpc_closed_loop_run: nsteps must be >= 1");
     if (planner != MPC_PLANNER_SKIDPAD && planner != MPC_PLANNER_STEP) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: unknown planner");
     if (!state || !target_vel || !u0_out) return fail(h, MPC_EINVAL, "mpc_closed_loop_step: state, target_vel and u0_out are required");
@@ -285,6 +314,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
                             int *status_out, int *iters_out)
 {
     if (int rc = check_batch(h, B, "mpc_ofl_closed_loop_run")) return rc;
+    ON_HANDLE_DEVICE(h);
     if (h->cfg.kind != MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: handle is not an OFL controller");
     if (nsteps < 1 || !state10 || !ekf_x || !ekf_P || !target_vel || !q_diag_host || !r_diag_host || !u0_out)
         return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: missing argument");
@@ -306,6 +336,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
 {
     if (!h || !host16) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
+    ON_HANDLE_DEVICE(h);
     HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->last_iters, h->last_status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->stats16));
     HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
