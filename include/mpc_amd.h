@@ -79,7 +79,9 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out);
 void mpc_destroy(mpc_handle *h);
 const char *mpc_last_error(const mpc_handle *h); /* h may be NULL: last error of mpc_create */
 
-/* Optional per-scenario model parameters mp[B][6] (tyre / mass sweeps); NULL restores cfg.mp. */
+/* Optional per-scenario model parameters mp[B][6] (tyre / mass sweeps); NULL restores cfg.mp.  This call and
+ * mpc_set_cost_weights copy with a blocking hipMemcpy into the handle: the source must be complete, and no launch
+ * of this handle may be in flight on another stream. */
 int mpc_set_model_params(mpc_handle *h, const double *mp_per_scenario);
 
 /* Optional per-scenario cost weights cost[B][43] (device): diag of W (7 entries, as cfg.w) followed by W_e (6x6
