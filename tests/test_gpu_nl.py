@@ -20,7 +20,7 @@ def _scenarios(rng, B, vx=8.0):
                      rng.uniform(-0.2, 0.2, B), rng.uniform(-0.2, 0.2, B), rng.uniform(-0.05, 0.05, B)], axis=1)
 
 
-@pytest.mark.parametrize("N,Tf", [(50, 0.5), (20, 0.4)])
+@pytest.mark.parametrize("N,Tf", [(50, 0.5), (20, 0.4), (10, 0.5), (64, 0.64), (30, 0.3), (40, 0.4)])
 def test_nl_solve_matches_checker_cold_and_warm(orc80, N, Tf):
     import torch
     from oracle import oracle as O
