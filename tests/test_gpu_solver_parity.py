@@ -20,11 +20,12 @@ def _tol(u_ref, umax=0.9):
     return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
 
 
-# horizons 10..64 in steps the library instantiates run register-resident; 54, 80, 100 and 128 take the any-horizon kernel
+# horizons 10, 20, 30, 40, 50 and 64 run register-resident; 54, 80, 100 and 128 take the any-horizon kernel
 # (one and two stages per lane, and its largest size)
 @pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("L", 10, 0.5), ("OFL", 50, 0.5), ("L", 64, 0.64),
                                        ("L", 54, 0.54), ("OFL", 80, 0.8), ("L", 100, 1.0), ("L", 128, 1.28),
-                                       ("L", 7, 0.07), ("L", 2, 0.02), ("OFL", 3, 0.03)])
+                                       ("L", 7, 0.07), ("L", 2, 0.02), ("OFL", 3, 0.03),
+                                       ("L", 20, 0.2), ("OFL", 30, 0.3), ("L", 40, 0.4)])
 def test_solve_only_matches_checker(orc80, kind, N, Tf):
     import torch
     from oracle import oracle as O
