@@ -226,6 +226,12 @@ def test_lpv_controller_sequence_horizon_80(orc80):
     _lpv_sequence(orc80, 80, 0.8, nsteps=6)
 
 
+@pytest.mark.parametrize("N,Tf,nsteps", [(10, 0.5, 8), (64, 0.64, 6), (100, 1.0, 4), (128, 1.28, 3)])
+def test_lpv_controller_sequence_other_horizons(orc80, N, Tf, nsteps):
+    """Smallest and largest register-resident horizon, and the any-horizon kernel up to its largest size."""
+    _lpv_sequence(orc80, N, Tf, nsteps=nsteps)
+
+
 def _lpv_sequence(orc80, N, Tf, nsteps=12):
     from oracle import oracle as O
     from mpc_amd.controllers import LPVOcp
