@@ -37,6 +37,31 @@ def test_ctypes_binding_covers_the_header(lib_path):
     _lib.load()                                   # sets argtypes on every symbol; raises if one is missing
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every declaration of include/mpc_amd.h against the argument list its ctypes binding sets: number of arguments and
+    the kind of each (pointer, double, int), and the return type."""
+    from mpc_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mpc_amd.h")).read(), flags=re.S)
+    decls = re.findall(r"\b(int|void|const char \*)\s*(mpc_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    assert len(decls) == len(_lib._SIGS)
+
+    def kind_c(arg):
+        return "ptr" if "*" in arg else "double" if re.search(r"\bdouble\b", arg) else "int"
+
+    def kind_py(t):
+        if t is ctypes.c_double:
+            return "double"
+        if t is ctypes.c_int:
+            return "int"
+        return "ptr"
+
+    for ret, name, args in decls:
+        args = [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]
+        argtypes, restype = _lib._SIGS[name]
+        assert [kind_c(a) for a in args] == [kind_py(t) for t in argtypes], name
+        assert {"int": ctypes.c_int, "void": None, "const char *": ctypes.c_char_p}[ret] is restype, name
+
+
 def test_config_struct_matches_header_layout(tmp_path):
     """The ctypes mirror against the C compiler's layout of struct mpc_config in include/mpc_amd.h, field by field."""
     import subprocess
