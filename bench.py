@@ -4,15 +4,21 @@
 One "step" = one fused closed-loop step (plan -> linearise/condense -> QP solve -> RK4 plant -> lap count,
 plus the EKF in the output-feedback workload) for every scenario of the batch.  Default workload (c2): LMPC2,
 B = 4096 perturbed skidpad initial states per GPU, horizon 50, dt 0.01, vx 8, numpy default_rng(rank) draws, state
-resident in HBM.  With --gpus G every rank runs its own scenarios (weak scaling, no collective in the loop; one RCCL
-all-reduce of the statistics vector at the end).  Other workloads (--workload): c3 LPV N=80 with per-scenario speeds,
-c4 output-feedback OFL + EKF with measurement noise, c5 nonlinear SQP with a tyre/mass sweep.
+resident in HBM.  Other workloads (--workload): c3 LPV N=80 with per-scenario speeds, c4 output-feedback OFL + EKF with
+measurement noise, c5 nonlinear SQP with a tyre/mass sweep.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: under torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 every rank runs its own scenarios (weak scaling, no collective in the loop; one all-reduce of the
+statistics vectors, sums and maxima, at the end).  Started without a launcher (WORLD_SIZE unset), the script starts
+the N ranks itself as fresh child processes under torch.distributed.run, before anything touches a GPU; started under
+torch.distributed.run it is one of the ranks.  --dry-run exercises that multi-rank path on the CPU (gloo, fabricated
+per-rank statistics, no kernel).
 
 The timed region starts at closed-loop step 50 of every scenario (c2; 10/20/5 for c3/c4/c5), after the constrained
 transient from the perturbed initial states: with --warmup W below that, the remaining steps run during set-up
-(reported as config.setup_steps).
+(reported as config.setup_steps).  After the timed region the script also times single-step launches (the p50 / p99
+step latency of the metric) and, for c2, one 1000-step launch far from the transient (solver.steady_state_*).
 """
 from __future__ import annotations
 
@@ -44,11 +50,12 @@ def ipm_flops(N: int) -> float:
     return N ** 3 / 3 + 9 * N * N + 100 * N
 
 
-def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0) -> float:
+def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0, ncomp: int = 3) -> float:
     """FP64 flops one scenario-step needs with the method that is run (symmetry and zero weights exploited).
     c2/c4 (speed constant, problem condensed once per launch and shared): planner 60(N+1); unconstrained minimiser as
-    an affine map of the step's data, 3 reference components + 5 state terms: 2(3N^2 + 5N); bound check 10N; RK4 400;
-    c4 adds the EKF (two 10x10x10 products, 7x7 solve with 10 right-hand sides, gain products) ~ 8000.
+    an affine map of the step's data, `ncomp` weighted reference components (2 with the yaml's weights: the x weight is
+    zero) + 5 state terms: 2(ncomp N^2 + 5N); bound check 10N; RK4 400; c4 adds the EKF (two 10x10x10 products, 7x7
+    solve with 10 right-hand sides, gain products) ~ 8000.
     c3 (condensed per scenario and step): stage model 130N; prediction columns and gradient 16N^2; Hessian, 3 weighted
     outputs, N^3 + 6N^2; LDL' N^3/3 + 2N^2.
     c5, per SQP iteration: RK4 roll-out 160N; RK4 derivative 700N; prediction columns 52N^2/2; Hessian, 5 weighted
@@ -56,12 +63,19 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
     Every interior-point iteration adds ipm_flops(N)."""
     plan = 60 * (N + 1) + 400
     if workload in ("c2", "c4"):
-        fixed = plan + 2 * (3 * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)
+        fixed = plan + 2 * (ncomp * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)
     elif workload == "c3":
         fixed = plan + 130 * N + 16 * N * N + N ** 3 + 6 * N * N + N ** 3 / 3 + 2 * N * N
     else:
         fixed = plan + mean_sqp * (860 * N + 26 * N * N + 5 * N ** 3 / 3 + 4 * N * N + N ** 3 / 3 + 2 * N * N)
     return fixed + ipm_flops(N) * mean_iters
+
+
+def weighted_reference_components(ocp) -> int:
+    """How many of the three reference components (x, y, sin psi) carry weight in the stage or terminal cost: the
+    cached affine map of the fixed-model kernel has one N x N block per such component."""
+    W, We = np.asarray(ocp.W), np.asarray(ocp.W_e)[:6, :6]
+    return int(sum(bool(W[c, c] != 0.0 or np.any(We[c, :] != 0.0) or np.any(We[:, c] != 0.0)) for c in range(3)))
 
 
 def algorithmic_bytes(workload: str, N: int) -> float:
@@ -72,25 +86,50 @@ def algorithmic_bytes(workload: str, N: int) -> float:
     return (8 + 3 + 1 + extra) * 8 * 2
 
 
+def host_threads() -> int:
+    """Threads the CPU baseline runs on: the cores this process may use, capped by OMP_NUM_THREADS."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(avail, cap) if cap > 0 else avail)
+
+
 def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
-    """The CPU restatement timed on this host, OpenMP over scenarios, on a bounded sample of the workload."""
-    if workload == "c4":
-        return None          # the checker composes the output-feedback loop in Python; it has no timed batch loop
+    """The CPU restatement timed on this host, OpenMP over scenarios, on a bounded sample of the workload.  As a tuned
+    CPU controller would, it takes the unconstrained minimiser (one Riccati pass) where that satisfies the bounds and
+    runs its interior point only on the other steps."""
     from oracle import oracle as O
     O.build()
     orc = O.Oracle("f64")
+    orc.set_unconstrained_first(True)
     kind, N, Tf = WORKLOADS[workload]["kind"], WORKLOADS[workload]["N"], WORKLOADS[workload]["Tf"]
     cfg = O.make_cfg(kind, N, Tf, sqp_tol=1e-30, sqp_max_iter=3) if kind == "NL" else O.make_cfg(kind, N, Tf)
-    st = initial_states(nscen, 0)
-    laps = np.zeros(nscen, np.int32); pp = np.zeros(nscen)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    t0 = time.perf_counter()
-    orc.skidpad_run(cfg, st, laps, pp, VX, nsteps, record=False)
-    dtm = time.perf_counter() - t0
+    if workload == "c4":
+        rng = np.random.default_rng(2)
+        x = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, -10.0]), (nscen, 1))
+        x[:, 9] = rng.uniform(-12.0, -8.0, nscen)
+        est = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (nscen, 1))
+        est[:, 1] += rng.normal(0, 0.05, nscen); est[:, 5] += rng.normal(0, 0.02, nscen)
+        P = np.tile(np.diag(O.EKF_P0_DIAG), (nscen, 1, 1))
+        noise = rng.standard_normal((nsteps, nscen, 7)) * O.EKF_R_DIAG
+        t0 = time.perf_counter()
+        orc.ofl_run(cfg, x, est, P, 15.0, nsteps, noise=noise, record=False)
+        dtm = time.perf_counter() - t0
+        what = "output-feedback closed-loop steps (OFL controller + EKF, noisy measurements"
+    else:
+        st = initial_states(nscen, 0)
+        laps = np.zeros(nscen, np.int32); pp = np.zeros(nscen)
+        t0 = time.perf_counter()
+        orc.skidpad_run(cfg, st, laps, pp, VX, nsteps, record=False)
+        dtm = time.perf_counter() - t0
+        what = f"closed-loop steps ({kind} controller, vx={VX}"
     out = {"value": nscen * nsteps / dtm, "unit": "scenario-steps/s", "cores": threads, "kind": "port",
-           "sample": f"{nscen} scenarios x {nsteps} closed-loop steps ({kind} controller, N={N}, vx={VX}; transient "
-                     f"included), oracle/mpc_oracle.c double build, OpenMP over scenarios, {dtm:.1f} s"}
+           "sample": f"{nscen} scenarios x {nsteps} {what}, N={N}; transient included), oracle/mpc_oracle.c double "
+                     f"build, unconstrained minimiser first, OpenMP over scenarios on {threads} threads, {dtm:.1f} s"}
     if workload == "c2":
         # one scenario on one thread, a call per step: the latency a single controller sees on this host (the
         # reference reports the median of its per-solve run times, plot_generator.py:1160-1191)
@@ -103,6 +142,7 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
         out["single_scenario"] = {"p50_step_latency_ms": 1e3 * float(np.median(lat)), "p99_step_latency_ms":
                                   1e3 * float(np.percentile(lat, 99)), "cores": 1,
                                   "sample": "default skidpad start, 1000 closed-loop steps, one call per step"}
+    orc.set_unconstrained_first(False)
     return out
 
 
@@ -169,6 +209,60 @@ def build_workload(name: str, B: int, rank: int, dev, steps_total: int):
     raise ValueError(name)
 
 
+SUM_KEYS = ("scenario_steps", "ipm_iterations", "constrained_solves", "status_nonzero", "sqp_iterations", "sum_abs_u0")
+MAX_KEYS = ("elapsed_s", "max_abs_u0", "max_complementarity", "max_residual")
+
+
+def reduce_statistics(sums: dict, maxima: dict, device=None) -> tuple[dict, dict]:
+    """The only exchange between the ranks: the per-rank statistics as one SUM and one MAX vector through
+    mpc_amd.sharding.allreduce_stats (RCCL for device tensors, gloo on the CPU)."""
+    import torch
+    from mpc_amd.sharding import allreduce_stats
+    sv = torch.tensor([float(sums[k]) for k in SUM_KEYS], dtype=torch.float64, device=device)
+    mv = torch.tensor([float(maxima[k]) for k in MAX_KEYS], dtype=torch.float64, device=device)
+    allreduce_stats(sv, mv)
+    return dict(zip(SUM_KEYS, sv.tolist())), dict(zip(MAX_KEYS, mv.tolist()))
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """Starts n ranks of this script under torch.distributed.run as a child process (nothing in this process has
+    touched a GPU) and passes the child's output through; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """The multi-rank path without a GPU: every rank fabricates the statistics of "its" scenarios, the vectors go
+    through the same reduction, rank 0 prints the line."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    from mpc_amd.sharding import shard_bounds
+    B = args.batch or WORKLOADS[args.workload]["B"]
+    lo, hi = shard_bounds(B * world, rank, world)
+    sums = {"scenario_steps": (hi - lo) * args.steps, "ipm_iterations": 2.0 * (hi - lo) * args.steps,
+            "constrained_solves": 0.5 * (hi - lo) * args.steps, "status_nonzero": 0, "sqp_iterations": 0, "sum_abs_u0": 0.1 * (hi - lo)}
+    maxima = {"elapsed_s": 1.0 + rank, "max_abs_u0": 0.1 * (rank + 1), "max_complementarity": 1e-16, "max_residual": 1e-13}
+    sums, maxima = reduce_statistics(sums, maxima)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": sums["scenario_steps"] / maxima["elapsed_s"], "unit": "scenario-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "statistics": {"sum": sums, "max": maxima}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+METRIC = "MPC QP solves/sec (node, batched skidpad scenarios) + p50 step latency"
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +271,9 @@ def main() -> None:
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--batch", type=int, default=None, help="scenarios per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--per-step-launch", action="store_true", help="c2 only: one kernel launch per closed-loop step")
+    ap.add_argument("--per-step-launch", action="store_true", help="one kernel launch per closed-loop step in the timed region")
+    ap.add_argument("--latency-launches", type=int, default=None, help="single-step launches timed after the run (default 200; 0 = none)")
+    ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing only, on the CPU (gloo), no kernel")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if args.steps is None:
@@ -185,18 +281,24 @@ def main() -> None:
     transient = {"c2": 50, "c3": 10, "c4": 20, "c5": 5}[args.workload]
     if args.warmup is None:
         args.warmup = transient
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # this process never touches a GPU
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting {world}", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     # The workloads time closed-loop steps from step `transient` of every scenario on (the heavily constrained start from
     # the perturbed initial states is warm-up by definition).  A run asked for fewer warm-up steps advances the scenarios
     # through the missing ones during set-up, so the timed steps are the same steps of the same trajectories.
     settle = max(0, transient - args.warmup)
-    if args.per_step_launch and args.workload != "c2":
-        ap.error("--per-step-launch is implemented for the c2 workload")
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -206,7 +308,9 @@ def main() -> None:
 
     B = args.batch or wl["B"]
     N = wl["N"]
-    sim, run = build_workload(args.workload, B, rank, dev, args.steps + args.warmup + settle)
+    nlat = args.latency_launches if args.latency_launches is not None else (0 if args.per_step_launch else (50 if args.workload == "c5" else 200))
+    extra = nlat + (1000 if args.workload == "c2" else 0)
+    sim, run = build_workload(args.workload, B, rank, dev, args.steps + args.warmup + settle + extra)
     if settle:
         run(settle)
 
@@ -221,7 +325,7 @@ def main() -> None:
     tw0 = time.perf_counter()
     if args.per_step_launch:
         for _ in range(args.warmup):
-            sim.step()
+            run(1)
     elif args.warmup:
         run(args.warmup)
     barrier()
@@ -229,6 +333,7 @@ def main() -> None:
 
     # Timed region: exactly `steps` closed-loop steps of every scenario.  Default: ONE launch carries each
     # scenario through all steps (scenarios are independent); --per-step-launch issues one launch per step.
+    # Launch durations come from HIP events on the stream the kernels are launched on (torch's current stream).
     nlaunch = args.steps if args.per_step_launch else 1
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlaunch)]
     iters_hist = torch.zeros((nlaunch, B), dtype=torch.int32, device=dev)
@@ -238,7 +343,7 @@ def main() -> None:
         for i in range(args.steps):
             sim.iters = iters_hist[i]
             ev[i][0].record()
-            sim.step()
+            run(1)
             ev[i][1].record()
     else:
         sim.iters = iters_hist[0]
@@ -249,32 +354,57 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
 
     st16 = sim.ocp.stats()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    status_timed = sim.status.clone()
     n_constr = float((iters_hist > 0).sum().item()) if args.per_step_launch else float(st16["n_constrained"])
-    stats = torch.tensor([float(iters_hist.sum().item()), n_constr, float((sim.status != 0).sum().item()),
-                          float(st16["sum_sqp_iterations"])], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # RCCL: the only collective of the path
-    elapsed = float(t.item())
+    sums = {"scenario_steps": B * args.steps, "ipm_iterations": float(iters_hist.sum().item()), "constrained_solves": n_constr,
+            "status_nonzero": float((status_timed != 0).sum().item()), "sqp_iterations": float(st16["sum_sqp_iterations"]),
+            "sum_abs_u0": float(st16["sum_abs_u0"])}
+    maxima = {"elapsed_s": elapsed, "max_abs_u0": float(st16["max_abs_u0"]), "max_complementarity": float(st16["max_complementarity"]),
+              "max_residual": float(st16["max_residual"])}
+    sums, maxima = reduce_statistics(sums, maxima, dev)       # RCCL: the only collective of the path
+    elapsed = maxima["elapsed_s"]
     kernel_ms = np.array([a.elapsed_time(b) for a, b in ev])
     steps_per_launch = args.steps / nlaunch
 
+    # After the timed region: the step-latency distribution (one launch per closed-loop step, a HIP event pair around
+    # each) and, for c2, a 1000-step launch in the steady state that follows the transient.
+    lat_ms = kernel_ms if args.per_step_launch else None
+    if nlat > 0:
+        sim.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        lev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlat)]
+        for a, b in lev:
+            a.record(); run(1); b.record()
+        torch.cuda.synchronize(dev)
+        lat_ms = np.array([a.elapsed_time(b) for a, b in lev])
+    steady = None
+    if args.workload == "c2" and not args.per_step_launch:
+        first = settle + args.warmup + args.steps + nlat
+        sa, sb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sa.record(); run(1000); sb.record()
+        torch.cuda.synchronize(dev)
+        steady = {"first_closed_loop_step": first, "steps": 1000, "launch_ms": sa.elapsed_time(sb),
+                  "scenario_steps_per_s_per_gpu": B * 1000 / (sa.elapsed_time(sb) * 1e-3),
+                  "mean_ipm_iterations_per_scenario_step": float(sim.iters.sum().item()) / (B * 1000)}
+
     if rank == 0:
-        total = B * world * args.steps
-        mean_iters = float(stats[0].item()) / total
-        mean_sqp = float(stats[3].item()) / total
-        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp)
+        total = sums["scenario_steps"]
+        mean_iters = sums["ipm_iterations"] / total
+        mean_sqp = sums["sqp_iterations"] / total
+        ncomp = weighted_reference_components(sim.ocp) if args.workload in ("c2", "c4") else 3
+        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp, ncomp)
         launch_s = float(kernel_ms.mean()) * 1e-3
         ach_tflops = flops * B * steps_per_launch / launch_s / 1e12
         out = {
-            "metric": "MPC QP solves/sec (node, batched skidpad scenarios) + p50 step latency",
+            "metric": METRIC,
             "value": total / elapsed,
             "unit": "scenario-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "p50_step_latency_ms": float(np.median(kernel_ms)) / steps_per_launch,
-            "p99_step_latency_ms": float(np.percentile(kernel_ms, 99)) / steps_per_launch,
+            "p50_step_latency_ms": float(np.median(lat_ms)) if lat_ms is not None else None,
+            "p99_step_latency_ms": float(np.percentile(lat_ms, 99)) if lat_ms is not None else None,
+            "step_latency_sample": (f"{len(lat_ms)} single-step launches of all {B} scenarios, HIP events per launch, "
+                                    + ("the timed region itself" if args.per_step_launch else
+                                       f"closed-loop steps {settle + args.warmup + args.steps}.. after the timed region")) if lat_ms is not None else None,
             "launch_mode": "per-step" if args.per_step_launch else f"fused ({args.steps} steps per launch)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -282,11 +412,14 @@ def main() -> None:
                        "parallelism": f"scenario-sharded x{world}",
                        "first_timed_closed_loop_step": settle + args.warmup, "setup_steps": settle},
             "solver": {"mean_ipm_iterations_per_scenario_step": mean_iters,
-                       "constrained_qp_per_scenario_step": float(stats[1].item()) / total,
+                       "constrained_qp_per_scenario_step": sums["constrained_solves"] / total,
                        "mean_sqp_iterations_per_scenario_step": mean_sqp if args.workload == "c5" else None,
-                       "status_nonzero_last_launch": int(stats[2].item()),
-                       "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(torch.bincount(sim.status.long()).tolist()) if v},
-                       "transient_scenario_steps_per_s": (B * world * args.warmup / t_warm) if args.warmup else None},
+                       "status_nonzero_last_launch": int(sums["status_nonzero"]),
+                       "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(torch.bincount(status_timed.long()).tolist()) if v},
+                       "max_abs_u0": maxima["max_abs_u0"], "max_complementarity": maxima["max_complementarity"],
+                       "max_residual": maxima["max_residual"],
+                       "transient_scenario_steps_per_s": (B * world * args.warmup / t_warm) if args.warmup else None,
+                       "steady_state": steady},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": measured_traffic(args),
                          "kernel": wl["kernel"], "avg_launch_ms": launch_s * 1e3,
@@ -297,7 +430,7 @@ def main() -> None:
                                  "peak_GBs": PEAK_HBM_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = {"c2": (1024, 300), "c3": (256, 40), "c4": (0, 0), "c5": (512, 20)}[args.workload]
+            sample = {"c2": (1024, 300), "c3": (256, 40), "c4": (512, 100), "c5": (512, 20)}[args.workload]
             out["cpu_baseline"] = cpu_baseline(args.workload, *sample)
         print(json.dumps(out))
     if world > 1:

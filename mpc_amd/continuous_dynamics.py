@@ -17,7 +17,7 @@ _MEASURED = [0, 1, 2, 3, 4, 6, 7]          # everything but vy (and the disturba
 class Dynamics:
     """continuous_dynamics.py:17.  x = [px, py, cos, sin, vx, vy, r, delta(, delta_dist, d_f)]."""
 
-    def __init__(self, dt=0.002, disturbance: bool = False, device=None):
+    def __init__(self, dt=0.002, disturbance: bool = False, device=None, _host_only: bool = False):
         self.m, self.I_z, self.wbase, self.x_cg = 180, 294, 1.53, 0.57      # hard-coded in the reference (:21-24)
         self.lf = self.x_cg * self.wbase
         self.lr = (1 - self.x_cg) * self.wbase
@@ -29,8 +29,10 @@ class Dynamics:
         self.measurement_matrix[np.arange(7), _MEASURED] = 1
         self.measurement_noises = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])
         self.rng = np.random.default_rng(1)
-        self.device = _dev.require_gpu(device)
-        self._lib = _lib.load()
+        # _host_only: the measurement model alone (selection matrix, noise draws), for use without a GPU; the plant
+        # model, RK4 and the EKF Jacobian need the device
+        self.device = None if _host_only else _dev.require_gpu(device)
+        self._lib = None if _host_only else _lib.load()
         self._mp = np.array([self.m, self.I_z, self.lf, self.lr, self.Cf, self.Cr], dtype=np.float64)
 
     def get_tyre_stiffness(self) -> tuple[float, float]:
@@ -94,6 +96,14 @@ class Dynamics:
         """Selection of the measured channels plus the reference's noise term: ONE scalar drawn from
         N(len(x), 1) scaled per channel (continuous_dynamics.py:216-220)."""
         return np.asarray(x)[_MEASURED] + self.measurement_noises * self.rng.normal(len(x))
+
+    def measurement_noise(self, n_steps: int, batch: int, literal: bool = False) -> np.ndarray:
+        """Additive measurement noise (n_steps, batch, 7) for the batched output-feedback loop.  literal=False: an
+        independent N(0, 1) draw per channel, scaled by the channel's sigma (what a noisy measurement means).
+        literal=True: what measure_state_noise adds, one N(len(x), 1) scalar per measurement scaled per channel."""
+        if literal:
+            return self.rng.normal(self.nx, 1.0, (n_steps, batch, 1)) * self.measurement_noises
+        return self.rng.standard_normal((n_steps, batch, 7)) * self.measurement_noises
 
     def measure_state_noiseless(self, x):
         return np.asarray(x, dtype=np.float64)[_MEASURED]

@@ -527,14 +527,17 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             const double gscale = fmax(1.0, vmaxabs<R>(g));
             const double lam0 = fmax(1.0, 0.01 * gscale);
             Vec<R> tpu, tmu, lpu, lmu, tpd, tmd, lpd, lmd;
+            auto cold_start = [&]() {
 #pragma unroll
-            for (int q = 0; q < R; q++) {
-                U.v[q] = 0.0;
-                tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
-                lpu.v[q] = valid[q] ? lam0 : 0.0; lmu.v[q] = lpu.v[q];
-                tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
-                lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
-            }
+                for (int q = 0; q < R; q++) {
+                    U.v[q] = 0.0;
+                    tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
+                    lpu.v[q] = valid[q] ? lam0 : 0.0; lmu.v[q] = lpu.v[q];
+                    tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
+                    lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
+                }
+            };
+            cold_start();
             bool warm = warm_ok;
             if (warm) {
                 // the previous solve moved one stage ahead, slacks pushed back inside, multipliers lifted to a common
@@ -565,7 +568,8 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 }
             }
             const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
-            double res_prev = 1e300;
+            double res_prev = 1e300, mu_last = 0.0, res_last = 0.0;
+            bool acc_last = false, rec_ok = true;
             Vec<R> U_last = U;
 #pragma unroll 1
             for (;;) {
@@ -625,22 +629,31 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 if (warm && iters == 0 && res > IPM_WARM_RES_MAX) {
                     // the problem moved too far from the previous one: fall back to the cold start
                     warm = false;
-#pragma unroll
-                    for (int q = 0; q < R; q++) {
-                        U.v[q] = 0.0;
-                        tpu.v[q] = valid[q] ? umax : 1.0; tmu.v[q] = tpu.v[q];
-                        lpu.v[q] = valid[q] ? lam0 : 0.0; lmu.v[q] = lpu.v[q];
-                        tpd.v[q] = validd[q] ? fmax(up_d[q], 0.1 * dmax) : 1.0; tmd.v[q] = validd[q] ? fmax(-lo_d[q], 0.1 * dmax) : 1.0;
-                        lpd.v[q] = validd[q] ? lam0 : 0.0; lmd.v[q] = lpd.v[q];
-                    }
+                    cold_start();
                     U_last = U;
                     continue;
                 }
-                if (mu <= cfg.tol_mu && (res <= cfg.tol_res || res >= 0.5 * res_prev)) break;
-                if (mu <= 1e-3 * cfg.tol_mu) { if (res > 1e3 * cfg.tol_res) status = 2; break; }   // see interior_point()
-                if (!(mu == mu)) { U = U_last; status = 2; break; }
-                if (iters >= cfg.max_iter) { status = 2; break; }
-                U_last = U;
+                // exit rules: see interior_point()
+                const bool finite = fabs(mu) < 1e300;
+                const bool acc = finite && mu <= 10.0 * cfg.tol_mu && res <= 1e3 * cfg.tol_res;
+                if (acc_last && !acc) { U = U_last; mu = mu_last; res = res_last; rec_ok = false; break; }
+                if (finite && mu <= cfg.tol_mu && res <= cfg.tol_res) break;
+                if (acc && (res >= 0.5 * res_prev || mu <= 1e-3 * cfg.tol_mu)) break;
+                if (!finite || mu <= 1e-3 * cfg.tol_mu || iters >= cfg.max_iter) {
+                    if (acc) break;
+                    if (warm && !(iters >= cfg.max_iter)) {      // once more from the cold start
+                        warm = false;
+                        cold_start();
+                        U_last = U;
+                        res_prev = 1e300; acc_last = false;
+                        iters++;
+                        continue;
+                    }
+                    if (!finite) { U = U_last; mu = mu_last; res = res_last; }
+                    rec_ok = false; status = 2;
+                    break;
+                }
+                U_last = U; mu_last = mu; res_last = res; acc_last = acc;
                 res_prev = res;
                 wave_sync();
                 lds_factor<R>(M, s_dinv, N, lane, dinv);
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 }
                 iters++;
             }
-            if (warm_rec) {
+            if (warm_rec && rec_ok) {
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     const int i = lane + WAVE * q;
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                     }
                 }
             }
-            warm_ok = warm_rec != nullptr && status == 0;
+            warm_ok = warm_rec != nullptr && status == 0 && rec_ok;
         } else
             warm_ok = false;
 

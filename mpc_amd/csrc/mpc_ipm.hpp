@@ -157,6 +157,13 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
     U = 0.0;
     tpu = umax; tmu = umax;
     tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax);
+    auto cold_start = [&]() {
+        U = 0.0;
+        tpu = umax; tmu = umax; lpu = lam0; lmu = lam0;
+        tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax); lpd = lam0; lmd = lam0;
+        if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
+        if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
+    };
     bool warm = prm.warm_mode != 0;
     if (warm) {
         // Start from the previous solve: its inputs (moved one stage ahead for the next closed-loop step), slacks pushed
@@ -183,7 +190,8 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
     if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
     if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
     const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
-    double res_prev = 1e300, U_last = 0.0;
+    double res_prev = 1e300, U_last = 0.0, mu_last = 0.0, res_last = 0.0;
+    bool acc_last = false, rec_ok = true;      // rec_ok: the multipliers belong to the returned inputs (warm-start record)
     int status = 0;
     iters = 0;
 #pragma unroll 1
@@ -216,21 +224,37 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
             // the problem moved too far from the previous one (e.g. a noisy state estimate): a start this close to the
             // boundary with residuals this large only blocks the steps.  Fall back to the cold start.
             warm = false;
-            U = 0.0;
-            tpu = umax; tmu = umax; lpu = lam0; lmu = lam0;
-            tpd = fmax(up_d, 0.1 * dmax); tmd = fmax(-lo_d, 0.1 * dmax); lpd = lam0; lmd = lam0;
-            if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
-            if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
+            cold_start();
             continue;
         }
-        // stop at the tolerances, or once the residual has reached the arithmetic's floor and stopped improving
-        if (mu <= prm.tol_mu && (res <= prm.tol_res || res >= 0.5 * res_prev)) break;
-        // complementarity far below its target: the Newton matrix is about to lose its small eigenvalues to rounding
-        // (the steering rows add dt^2 * sum(lambda/t) to every entry); accept a residual within 1000x of its tolerance
-        if (mu <= 1e-3 * prm.tol_mu) { status = res <= 1e3 * prm.tol_res ? 0 : 2; break; }
-        if (!(mu == mu)) { U = U_last; status = 2; break; }          // arithmetic broke down: keep the last finite iterate
-        if (iters >= prm.max_iter) { status = 2; break; }
-        U_last = U;
+        // Exit rules.  An iterate is `acceptable` when its complementarity is within 10x of the tolerance and its residual
+        // within 1000x of its own: close to the solution the Newton matrix (the steering rows add dt^2 * sum(lambda/t) to every
+        // entry) loses its small eigenvalues to rounding, the residual stops at a floor of a few 1e-12 of the gradient's
+        // size, and one step further the factorisation can break down altogether.  So: stop at the tolerances; stop at
+        // an acceptable iterate whose residual no longer halves or whose complementarity is already 1000x below its
+        // tolerance; and when the step taken from an acceptable iterate produced something worse or not finite, return
+        // that acceptable iterate.  A solve that breaks down otherwise is repeated from the cold start if it began from the
+        // previous solve's record; status 2 is left for what still fails.
+        const bool finite = fabs(mu) < 1e300;                        // false for NaN and infinity
+        const bool acc = finite && mu <= 10.0 * prm.tol_mu && res <= 1e3 * prm.tol_res;
+        if (acc_last && !acc) { U = U_last; mu = mu_last; res = res_last; rec_ok = false; break; }
+        if (finite && mu <= prm.tol_mu && res <= prm.tol_res) break;
+        if (acc && (res >= 0.5 * res_prev || mu <= 1e-3 * prm.tol_mu)) break;
+        if (!finite || mu <= 1e-3 * prm.tol_mu || iters >= prm.max_iter) {
+            if (acc) break;                                          // (the iteration cap at an acceptable iterate)
+            if (warm && !(iters >= prm.max_iter)) {
+                // a solve that started from the previous one's record broke down: once more from the cold start
+                warm = false;
+                cold_start();
+                res_prev = 1e300; acc_last = false;
+                iters++;
+                continue;
+            }
+            if (!finite) { U = U_last; mu = mu_last; res = res_last; }
+            rec_ok = false; status = 2;
+            break;
+        }
+        U_last = U; mu_last = mu; res_last = res; acc_last = acc;
         res_prev = res;
         // reciprocals of the slacks and multipliers, shared by everything below (a quotient costs ~3x a reciprocal)
         const double itpu = fast_rcp(tpu), itmu = fast_rcp(tmu), itpd = fast_rcp(tpd), itmd = fast_rcp(tmd);
@@ -319,11 +343,11 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         lpd = fma(alpha, dlpd, lpd); lmd = fma(alpha, dlmd, lmd);
         iters++;
     }
-    if (prm.warm) {
+    if (prm.warm && rec_ok) {
         gdouble *w = (gdouble *)prm.warm;
         if (valid) { w[lane] = U; w[WAVE + lane] = lpu; w[2 * WAVE + lane] = lmu; w[3 * WAVE + lane] = lpd; w[4 * WAVE + lane] = lmd; }
     }
-    IpmResult out = {U, mu, res, iters, status};
+    IpmResult out = {U, mu, res, iters, status, rec_ok && status == 0};
     return out;
 }
 

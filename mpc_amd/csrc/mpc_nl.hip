@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 const IpmResult r = interior_point<N, 3>(prm, lane, Hw, gq, up_d, lo_d, (ldouble *)s_wv);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
-                warm_ok = (warm_rec != nullptr) && r.status == 0;
+                warm_ok = (warm_rec != nullptr) && r.warm_valid;
             } else
                 warm_ok = false;
             const double step = wave_max(valid ? fabs(Un - U) : 0.0);

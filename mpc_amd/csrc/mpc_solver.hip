@@ -336,7 +336,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0};
             const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)(GENERAL ? s_wv : s_ref));   // both areas are dead by now
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
-            warm_ok = (warm_rec != nullptr) && r.status == 0;
+            warm_ok = (warm_rec != nullptr) && r.warm_valid;
         } else
             warm_ok = false;
         if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible

@@ -7,7 +7,8 @@ The controllers (LMPC2/LPVMPC/OFLMPC2/NLMPC) need acados/casadi/control and
 cannot be imported: no solver output is recorded here.
 
 The fixtures hold inputs and the reference's outputs only; no reference source
-text is stored.  Usage:  python oracle/make_golden.py [/root/reference]
+text is stored.  Usage:  python oracle/make_golden.py [/root/reference [fixture ...]]
+(fixture names, e.g. "measurement", restrict the run to those files; default: all)
 """
 import contextlib
 import io
@@ -19,6 +20,12 @@ import numpy as np
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+ONLY = set(sys.argv[2:])
+
+
+def save(name, **rec):
+    if not ONLY or name in ONLY:
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
 
 
 def main():
@@ -59,7 +66,7 @@ def main():
     rec["Cf_Cr"] = np.array([dyn.Cf, dyn.Cr])
     # the known-answer case of the survey: dt=0.01, x=[15,0.1,1,0,8,0,0,0], u=0.5
     rec["kat_x1"] = dyn.rk4_integraton(np.array([15, 0.1, 1.0, 0, 8.0, 0, 0, 0]), 0.5)
-    np.savez_compressed(os.path.join(OUT, "plant.npz"), **rec)
+    save("plant", **rec)
 
     # ---- EKF: Jacobians, and a full predict/update trace driven like StepSimulator.lsim ----
     rec = {}
@@ -93,7 +100,7 @@ def main():
     rec.update(ekf_u=u, ekf_dt=np.array(dt), ekf_x_pred=np.array(tr_xp), ekf_P_pred=np.array(tr_Pp),
                ekf_x=np.array(tr_x), ekf_P=np.array(tr_P), ekf_true=np.array(tr_true), ekf_y=np.array(tr_y),
                ekf_red=ekf.estimated_red_state())
-    np.savez_compressed(os.path.join(OUT, "ekf.npz"), **rec)
+    save("ekf", **rec)
 
     # ---- planners ----
     rec = {}
@@ -146,7 +153,7 @@ def main():
         poses.append([px, py, hd]); wps.append(w.copy()); absw.append(ab.copy())
     rec.update(st_pose=np.array(poses), st_wp=np.array(wps), st_abs=np.array(absw), st_N=np.array(N),
                st_dt=np.array(dt), st_v=np.array(v))
-    np.savez_compressed(os.path.join(OUT, "planners.npz"), **rec)
+    save("planners", **rec)
 
     # ---- planner speed profile (laps outside 0..7), progress2speed, request_desired_speed ----
     rec = {}
@@ -178,7 +185,7 @@ def main():
             for k, val in q.items():
                 rec[f"c{ci}_r{ri}_{k}"] = np.asarray(val)
     rec["ncases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(OUT, "planner_speed_profile.npz"), **rec)
+    save("planner_speed_profile", **rec)
 
     # ---- step planner with a ramped step (ramp_length > 0, step_planning.py:75-79) ----
     rec = {}
@@ -194,7 +201,23 @@ def main():
                     f"c{ci}_speeds": np.array(spds), f"c{ci}_p0": np.array(p0s), f"c{ci}_N": np.array(N),
                     f"c{ci}_dt": np.array(dt), f"c{ci}_v": np.array(v), f"c{ci}_ramp": np.array(ramp)})
     rec["ncases"] = np.array(3)
-    np.savez_compressed(os.path.join(OUT, "step_ramp.npz"), **rec)
+    save("step_ramp", **rec)
+
+    # ---- measurement model: measure_state_noiseless and measure_state_noise (continuous_dynamics.py:212-223).  The noisy
+    # one adds measurement_noises times ONE scalar drawn as rng.normal(len(x)), i.e. N(len(x), 1), from default_rng(1);
+    # three consecutive calls per model size are recorded, each on its own state.
+    rec = {}
+    mrng = np.random.default_rng(77)
+    for nx, dist in ((8, False), (10, True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dyn = Dynamics(0.01, disturbance=dist)
+        xs = mrng.uniform(-2, 2, (3, nx)); xs[:, 4] += 10
+        rec[f"x{nx}"] = xs
+        rec[f"y_noiseless{nx}"] = np.array([dyn.measure_state_noiseless(x) for x in xs])
+        rec[f"y_noisy{nx}"] = np.array([dyn.measure_state_noise(x) for x in xs])
+        rec[f"H{nx}"] = np.array(dyn.measurement_jacobian())
+    rec["sigma"] = np.array(dyn.measurement_noises)
+    save("measurement", **rec)
 
     # ---- known answers held by the reference: terminal_set.m:4-10 (A 5x5, B at vx=15, dt=0.02), values as printed ----
     A = np.array([[1.0, 0.3, 0.02, 0.0, 0.0],
@@ -203,7 +226,7 @@ def main():
                   [0.0, 0.0, -0.00219257, 0.8871941, -1.1200825],
                   [0.0, 0.0, 0.0, 0.0, 1.0]])
     B = np.array([0.0, 0.0, 0.0, 0.0, 0.02])
-    np.savez_compressed(os.path.join(OUT, "kat_terminal_set.npz"), A=A, B=B, dt=np.array(0.02), vx=np.array(15.0))
+    save("kat_terminal_set", A=A, B=B, dt=np.array(0.02), vx=np.array(15.0))
     print("wrote", sorted(os.listdir(OUT)))
 
 

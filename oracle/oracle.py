@@ -71,6 +71,10 @@ class Oracle:
         L.orc_skidpad_run.argtypes = [_dp, _dp, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, C.c_double, C.c_double,
                                       C.c_int]
         L.orc_skidpad_run.restype = C.c_long
+        L.orc_ofl_run.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp,
+                                  _ip, C.c_double, C.c_double, C.c_int]
+        L.orc_ofl_run.restype = C.c_long
+        L.orc_set_unconstrained_first.argtypes = [C.c_int]
         self.precision = precision
         # default solver tolerances: as tight as the arithmetic allows
         self.tol = (1e-13, 1e-15, 100) if precision == "f64" else (1e-17, 1e-18, 200)
@@ -177,6 +181,34 @@ class Oracle:
         iters = self.lib.orc_skidpad_run(_ptr(cfg), _ptr(states), laps.ctypes.data_as(_ip), _ptr(prev_progress),
                                          float(target_vel), B, int(nsteps), _ptr(uh), tol[0], tol[1], tol[2])
         return uh, int(iters)
+
+
+    def ofl_run(self, cfg, x10, est, P, target_vel, nsteps, noise=None, ramp_length=0.0, record=True, tol=None):
+        """simulator.py:206-281 for B scenarios: x10 / est (B,10) and P (B,10,10) are updated in place; noise (n,B,7)
+        is added to the measurements.  Returns (u (n,B), x (n,B,10), est (n,B,10), status (B,), iterations)."""
+        tol = tol or self.tol
+        B = x10.shape[0]
+        assert x10.flags.c_contiguous and est.flags.c_contiguous and P.flags.c_contiguous
+        uh = np.zeros((nsteps, B)) if record else None
+        xh = np.zeros((nsteps, B, 10)) if record else None
+        eh = np.zeros((nsteps, B, 10)) if record else None
+        status = np.zeros(B, np.int32)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
+        assert nz is None or nz.shape == (nsteps, B, 7)
+        iters = self.lib.orc_ofl_run(_ptr(cfg), _ptr(x10), _ptr(est), _ptr(P), float(target_vel), B, int(nsteps), _ptr(nz),
+                                     _ptr(EKF_Q_DIAG), _ptr(EKF_R_DIAG), float(ramp_length), _ptr(uh), _ptr(xh), _ptr(eh),
+                                     status.ctypes.data_as(_ip), tol[0], tol[1], tol[2])
+        return uh, xh, eh, status, int(iters)
+
+    def set_unconstrained_first(self, on: bool):
+        """Timed CPU baseline only: try the unconstrained minimiser (one Riccati pass) before the interior point."""
+        self.lib.orc_set_unconstrained_first(int(bool(on)))
+
+
+# EKF.py:28-32: P0, Q and R = diag(sigma) of CarEKF
+EKF_P0_DIAG = np.array([1, 1, 1, 1, 1, 10.0, 1.0, 1.0, 0.0, 1000000.0])
+EKF_Q_DIAG = np.array([0.05, 0.05, 0.01, 0.01, 0.001, 0.1, 0.01, 0.01, 0.0, 0.0])
+EKF_R_DIAG = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])
 
 
 # ---------------------------------------------------------------------------

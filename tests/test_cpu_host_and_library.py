@@ -146,3 +146,27 @@ def test_parameter_files_read_like_the_reference(tmp_path, monkeypatch):
     ref = LOcp(50, 0.5, _host_only=True, params=base)
     np.testing.assert_allclose(ctl.W_e[1:6, 1:6], 2 * 0.5 * ctl.P)
     np.testing.assert_allclose(ctl.P, ref.P)      # the reference's DARE takes R' = W[4,4] = 0, so r does not enter P
+
+
+def test_measurement_model_matches_reference_recording(golden):
+    """Dynamics.measure_state_noiseless / measure_state_noise against values recorded from the reference
+    (oracle/make_golden.py): the noisy form adds sigma times ONE scalar drawn from N(len(x), 1), from default_rng(1)
+    (continuous_dynamics.py:68-72,216-220)."""
+    from mpc_amd.continuous_dynamics import Dynamics
+    g = golden["measurement"]
+    for nx, dist in ((8, False), (10, True)):
+        dyn = Dynamics(0.01, disturbance=dist, _host_only=True)
+        np.testing.assert_array_equal(dyn.measurement_jacobian(), g[f"H{nx}"])
+        np.testing.assert_array_equal(dyn.measurement_noises, g["sigma"])
+        for i, x in enumerate(g[f"x{nx}"]):
+            np.testing.assert_array_equal(dyn.measure_state_noiseless(x), g[f"y_noiseless{nx}"][i])
+            np.testing.assert_allclose(dyn.measure_state_noise(x), g[f"y_noisy{nx}"][i], rtol=0, atol=1e-15)
+        # the quirk itself: every channel carries the same draw, centred on the state length
+        d = (g[f"y_noisy{nx}"] - g[f"y_noiseless{nx}"]) / g["sigma"]
+        assert np.allclose(d, d[:, :1], rtol=0, atol=1e-12) and abs(d.mean() - nx) < 2.0
+    # the tensor form used by the batched loop draws the same numbers in the same order
+    a = Dynamics(0.01, True, _host_only=True); b = Dynamics(0.01, True, _host_only=True)
+    lit = a.measurement_noise(3, 1, literal=True)
+    ref = np.array([b.measure_state_noise(np.zeros(10)) for _ in range(3)])
+    np.testing.assert_allclose(lit[:, 0], ref, rtol=0, atol=1e-15)
+    assert a.measurement_noise(4, 5).shape == (4, 5, 7)

@@ -61,3 +61,34 @@ def test_shard_bounds_properties():
     from mpc_amd.sharding import allreduce_stats
     a, b = allreduce_stats(torch.ones(3), torch.zeros(2))
     assert a.tolist() == [1, 1, 1] and b.tolist() == [0, 0]
+
+
+def test_bench_starts_its_own_ranks_and_reduces_through_the_sharding_helper():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (fresh child processes under
+    torch.distributed.run) and rank 0 prints one line for both; --dry-run keeps the ranks on the CPU (gloo) with
+    fabricated per-rank statistics, which travel through bench.reduce_statistics -> sharding.allreduce_stats exactly as
+    the measured ones do."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                          # one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    s, m = d["statistics"]["sum"], d["statistics"]["max"]
+    assert s["scenario_steps"] == 2 * 4096 * 20                     # SUM over the ranks
+    assert m["elapsed_s"] == 2.0 and m["max_abs_u0"] == 0.2         # MAX over the ranks (rank 1 reports 2.0 s)
+    assert d["value"] == s["scenario_steps"] / m["elapsed_s"]       # whole-job units over the slowest rank's time
+
+
+def test_reduce_statistics_is_identity_for_one_rank():
+    import bench
+    sums = {k: float(i + 1) for i, k in enumerate(bench.SUM_KEYS)}
+    maxima = {k: float(10 * (i + 1)) for i, k in enumerate(bench.MAX_KEYS)}
+    s, m = bench.reduce_statistics(sums, maxima)
+    assert s == sums and m == maxima

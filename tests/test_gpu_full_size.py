@@ -24,8 +24,9 @@ def _build(name, st, mp=None):
     return sim
 
 
-@pytest.mark.parametrize("name,nsteps,nsub,nref,ref_steps", [("c2", 1050, 64, 8, 200), ("c3", 60, 32, 3, 25),
-                                                               ("c5", 20, 64, 2, 10)])
+# step counts: the workloads' own run lengths (c2 50 + 1000, c3 500, c5 200)
+@pytest.mark.parametrize("name,nsteps,nsub,nref,ref_steps", [("c2", 1050, 64, 8, 200), ("c3", 500, 32, 3, 25),
+                                                               ("c5", 200, 64, 2, 10)])
 def test_full_batch_scenarios_are_independent_and_follow_checker(orc64, name, nsteps, nsub, nref, ref_steps):
     import torch
     import bench
@@ -60,7 +61,7 @@ def test_full_batch_scenarios_are_independent_and_follow_checker(orc64, name, ns
     if name == "c5":
         assert set(np.unique(status)) <= {0, 1}                       # 1 = the fixed three SQP iterations were used up
     else:
-        assert (status != 0).mean() <= 1e-3, np.bincount(status)
+        assert (status == 0).all(), np.bincount(status)                 # every solve of every step ended at its minimiser
     # a few scenarios of the full batch against the checker's loop
     us_h = us[:ref_steps, tidx[:nref]].cpu().numpy()
     for j in range(nref):

@@ -169,3 +169,30 @@ def test_out_of_reach_steering_start_is_relaxed_and_flagged(orc80):
             assert stt == status[b]
             assert (np.abs(U[b] - U_ref) <= _tol(U_ref)).all(), (kind, b, np.abs(U[b] - U_ref).max())
         assert np.isfinite(U).all()
+
+
+def test_lpv_steps_that_once_broke_the_interior_point(orc80, golden):
+    """Closed-loop steps of the LPV N=80 workload on which the interior point used to end without a minimiser (the
+    Newton matrix loses its definiteness to rounding when the complementarity passes 1e-15 with a steering-angle bound
+    active; about one solve in 1e5).  The inputs of those steps were recorded on the GPU (tools/lpv_fail_scan.py); they
+    must solve with status 0 to the input bar, started cold."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    d = golden["lpv_hard_steps"]
+    N, Tf = 80, 0.8
+    n = d["state"].shape[0]
+    cfg = O.make_cfg("LPV", N, Tf)
+    sim = SkidpadBatch(N, Tf, d["state"], starting_laps=d["lap"], model="LPV")
+    sim.prev_progress.copy_(torch.as_tensor(d["prev_progress"]))
+    sim.lin_x.copy_(torch.as_tensor(d["lin_x"])); sim.lin_u.copy_(torch.as_tensor(d["lin_u"]))
+    u0 = sim.step().cpu().numpy()
+    status = sim.status.cpu().numpy(); iters = sim.iters.cpu().numpy()
+    assert (status == 0).all(), status
+    assert (iters > 0).all()                                            # every one of them is a constrained solve
+    for b in range(n):
+        lx = np.ascontiguousarray(d["lin_x"][b]).copy(); lu = np.ascontiguousarray(d["lin_u"][b]).copy()
+        st, _, _, _, u_ref, _ = orc80.skidpad_step(cfg, d["state"][b], int(d["lap"][b]), float(d["prev_progress"][b]),
+                                                   float(d["state"][b, 4]), lx, lu)
+        assert st == 0
+        assert abs(u0[b] - u_ref) <= _tol(np.array([u_ref]))[0], (b, u0[b], u_ref, iters[b])
