@@ -159,7 +159,7 @@ def measured_traffic(args):
 WORKLOADS = {
     "c2": {"kind": "L", "N": 50, "Tf": 0.5, "B": 4096, "kernel": "k_mpc<50, fixed-model>",
            "text": "LMPC2 batched: 4096 perturbed skidpad initial states per GPU, fixed A,B (vx=8), N=50, dt=0.01, closed loop"},
-    "c3": {"kind": "LPV", "N": 80, "Tf": 0.8, "B": 8192, "kernel": "k_mpc_any<2>",
+    "c3": {"kind": "LPV", "N": 80, "Tf": 0.8, "B": 8192, "kernel": "k_mpc_lanes (stage-wise Riccati interior point, one lane per scenario)",
            "text": "LPVMPC batched: 8192 scenarios per GPU, per-scenario vx~U(6,12), N=80, dt=0.01, lin_mode reference, closed loop"},
     "c4": {"kind": "OFL", "N": 50, "Tf": 0.5, "B": 8192, "kernel": "k_mpc<50, fixed-model> (MODE_OFL)",
            "text": "OFLMPC2 + EKF batched: 8192 scenarios per GPU, step reference, side force d_f~U(-12,-8), noisy "

@@ -9,6 +9,13 @@
  * negative MPC_E* code; mpc_last_error() gives the text.  No exceptions cross this boundary and the
  * library owns nothing but the handle and its workspace.
  *
+ * Concurrency: a handle carries workspace that every launch of it uses (condensed Hessians, interior-point warm-start
+ * records, the scenario order of chained launches, the solver records mpc_get_stats reads).  Issue the calls of one
+ * handle one after the other on ONE stream; two launches of the same handle in flight at once race on that workspace.
+ * Different handles are independent.  The warm-start records tie a handle to the closed loops it advances: after
+ * replacing the state arrays with unrelated scenarios call mpc_reset_warm_start (a stale record is otherwise only
+ * rejected by its residual test, and the results stop being reproducible run to run).
+ *
  * Devices: a handle belongs to mpc_config.device.  Entry points that take a handle make that device
  * current while they run and give the caller's current device back on return; the stream and the
  * buffers passed must live on the handle's device.  Entry points without a handle run on the calling
@@ -41,6 +48,10 @@ extern "C" {
 
 #define MPC_MAX_HORIZON 128
 
+#define MPC_LAYOUT_AUTO 0
+#define MPC_LAYOUT_WAVE 1
+#define MPC_LAYOUT_LANE 2
+
 /* Controller definition; what the reference's constructors derive from parameters_*.yaml
  * (LMPC2.py:14-96, LPVMPC.py:10-92, OFLMPC2.py:16-100). */
 typedef struct mpc_config {
@@ -70,6 +81,10 @@ typedef struct mpc_config {
                           * point from the previous solve when that one hit a bound too; 1: always cold start */
     double step_ramp_length; /* MPC_PLANNER_STEP loops: progress over which the step reference rises (StepPlanner's
                               * ramp_length, utils/step_planning.py:51,75-79); 0 = the pure step the simulators use */
+    int solver_layout;   /* how scenarios map to the GPU (results agree to the solver tolerances, not bit for bit):
+                          * MPC_LAYOUT_AUTO; MPC_LAYOUT_WAVE: one wavefront per scenario, horizon condensed into a dense
+                          * N x N problem; MPC_LAYOUT_LANE: one lane per scenario, stage-wise Riccati interior point
+                          * (kinds L / OFL / LPV; not for mpc_ofl_closed_loop_run).  AUTO = LANE for MPC_KIND_LPV, else WAVE */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
@@ -106,7 +121,11 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
  *   wp      [B][N+1][4] car-frame waypoints, p [B][N+1] speeds, d_hat [B] (OFL) or NULL
  *   lin_x   [B][6][N+1], lin_u [B][N]  LPV prev_x / prev_u, read and updated (NULL otherwise)
  *   U_out   [B][N]; traj_out [B][N+1][7] or NULL; status_out [B], iters_out [B]
- *   status: 0 ok; 2 interior-point iteration cap; 3 speed differs from the exclusive fixed-model cache; 4 the start
+ *   status: 0 ok; 2 the interior point ended without a minimiser (iteration cap or breakdown of the arithmetic, also after
+ *   its cold restart); 3 speed differs from the exclusive fixed-model cache; 5 (closed-loop skidpad entry points) the lap
+ *   counter left 0..7, where the reference's planner switches to its speed profile (utils/path_planning.py:241-248) and
+ *   the fused loops keep the constant target speed: such steps differ from the reference (mpc_plan_skidpad_profile has
+ *   that branch); 4 the start
  *   steering angle lies so far outside its bound that the reference's QP is infeasible (acados raises there): the
  *   bound was widened along the fastest way back inside and that problem solved instead
  * MPC_KIND_NL (NLMPC.py:214-252): lin_u [B][N] is required and holds the SQP iterate, read as the starting point and
@@ -209,6 +228,11 @@ int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const doubl
  * ok_out [nc] (device) receives 1 where no image leaves the box, else 0. */
 int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, const double *eig_host, const double *A_host,
                          const double *B_host, const double *K_host, double umax, const double *c, int *ok_out);
+
+/* Forgets the interior-point warm-start records and the scenario order learnt from earlier launches: the next solve of
+ * every scenario starts cold.  No counterpart in the reference (acados keeps its iterate inside the solver object and the
+ * reference never resets it); for callers that reuse a handle for new scenarios. */
+int mpc_reset_warm_start(mpc_handle *h, void *stream);
 
 /* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
  * copied to a host array of 16 doubles after synchronising the stream:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmpc_amd.so")
-SOURCES = ["mpc_solver.hip", "mpc_generic.hip", "mpc_nl.hip", "mpc_aux.hip", "mpc_abi.hip"]
+SOURCES = ["mpc_solver.hip", "mpc_generic.hip", "mpc_lanes.hip", "mpc_nl.hip", "mpc_aux.hip", "mpc_abi.hip"]
 HEADERS = ["mpc_device.hpp", "mpc_wave.hpp", "mpc_ipm.hpp", "mpc_kernels.h", os.path.join("..", "..", "include", "mpc_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Machine LICM hoists the literal constants of the inlined math routines out of the in-kernel step loop and then

@@ -12,6 +12,7 @@ from . import _build
 KIND = {"L": 0, "OFL": 1, "LPV": 2, "NL": 3}
 PLANNER_SKIDPAD, PLANNER_STEP = 0, 1
 MAX_HORIZON = 128
+LAYOUT = {"auto": 0, "wave": 1, "lane": 2}
 
 
 class MpcConfig(C.Structure):
@@ -22,6 +23,7 @@ class MpcConfig(C.Structure):
         ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
         ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
         ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int), ("step_ramp_length", C.c_double),
+        ("solver_layout", C.c_int),
     ]
 
 
@@ -52,6 +54,7 @@ _SIGS = {
     "mpc_control_buffer_interp": ([_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_double, _vp], C.c_int),
     "mpc_invariance_check": ([_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _vp, _vp], C.c_int),
     "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),
+    "mpc_reset_warm_start": ([_vp, _vp], C.c_int),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -77,7 +77,8 @@ class _CondensedMpc:
 
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
-                 ipm_warm_start: bool = True, step_ramp_length: float = 0.0, _host_only: bool = False):
+                 ipm_warm_start: bool = True, step_ramp_length: float = 0.0, solver_layout: str = "auto",
+                 _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
@@ -103,6 +104,9 @@ class _CondensedMpc:
         # the step-reference closed loops generate their waypoints on the GPU: StepPlanner's ramp_length travels with
         # the controller definition (utils/step_planning.py:51)
         self._step_ramp = float(step_ramp_length)
+        # "wave": one wavefront per scenario on the condensed problem; "lane": one lane per scenario, stage-wise Riccati
+        # interior point; "auto": lane for the LPV controller, wave otherwise
+        self._layout = _lib.LAYOUT[solver_layout]
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
             self.device = None
             self.solver = None
@@ -163,6 +167,7 @@ class _CondensedMpc:
         cfg.lpv_lin_prev = 0
         cfg.ipm_cold_start = self._ipm_cold
         cfg.step_ramp_length = self._step_ramp
+        cfg.solver_layout = self._layout
         return cfg
 
     def stability(self):
@@ -273,6 +278,12 @@ class _CondensedMpc:
         v = float("nan") if vx is None else float(vx)
         rc = self.solver._lib.mpc_condense_fixed(self.solver.h, _dev.stream_ptr(self.device), v, int(bool(exclusive)))
         _lib.check(rc, self.solver.h, "mpc_condense_fixed")
+
+    def reset_warm_start(self):
+        """Forget what earlier solves left in the handle (interior-point warm-start records, launch order): call after
+        handing the controller unrelated scenarios."""
+        rc = self.solver._lib.mpc_reset_warm_start(self.solver.h, _dev.stream_ptr(self.device))
+        _lib.check(rc, self.solver.h, "mpc_reset_warm_start")
 
     def stats(self) -> dict:
         out = np.zeros(16)

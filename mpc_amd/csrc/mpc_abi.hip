@@ -9,7 +9,9 @@
 struct mpc_handle {
     mpc_config cfg;
     mpc::DevCfg dev;
-    double *Hws = nullptr;       // B * N * N condensed Hessians
+    bool lanes = false;          // one lane per scenario (mpc_config.solver_layout resolved)
+    double *lane_ws = nullptr;   // lanes: per-stage workspace, also the warm-start record
+    double *Hws = nullptr;       // B * N * N condensed Hessians (wave layout)
     int *sqp = nullptr;          // B SQP iteration counts of the last NL call
     double *ipm_ws = nullptr;    // B interior-point warm-start records (NULL: cold starts only)
     double *stat = nullptr;      // B * 4 solver records
@@ -23,7 +25,6 @@ struct mpc_handle {
     double sh_vx = 0.0;
     int sh_mask = 0;
     bool sh_on = false, sh_exclusive = false;
-    const int *last_iters = nullptr, *last_status = nullptr;
     int last_B = 0;
     std::string err;
 };
@@ -73,36 +74,52 @@ extern "C" {
 
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int mpc_create(const mpc_config *cfg, mpc_handle **out)
+// Argument checks shared by mpc_create and the handle-free entry point; returns NULL when the definition is usable.
+static const char *check_config(const mpc_config *cfg)
 {
-    if (!cfg || !out) return fail(nullptr, MPC_EINVAL, "mpc_create: null argument");
-    *out = nullptr;
-    if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_NL) return fail(nullptr, MPC_EINVAL, "mpc_create: unknown kind");
+    static thread_local char buf[160];
+    if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_NL) return "unknown kind";
     if (!mpc::horizon_supported(cfg->N)) {
-        char b[160];
-        snprintf(b, sizeof b, "mpc_create: horizon N=%d is outside 2..%d", cfg->N, MPC_MAX_HORIZON);
-        return fail(nullptr, MPC_EINVAL, b);
+        snprintf(buf, sizeof buf, "horizon N=%d is outside 2..%d", cfg->N, MPC_MAX_HORIZON);
+        return buf;
     }
-    if (cfg->B < 1 || !(cfg->dt > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: need B >= 1 and dt > 0");
-    if (!(cfg->step_ramp_length >= 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: step_ramp_length must be >= 0");
+    if (cfg->B < 1 || !(cfg->dt > 0.0)) return "need B >= 1 and dt > 0";
+    if (!(cfg->step_ramp_length >= 0.0)) return "step_ramp_length must be >= 0";
     if (cfg->kind == MPC_KIND_NL) {
-        if (!mpc::horizon_templated(cfg->N)) return fail(nullptr, MPC_EINVAL, "mpc_create: the NL controller needs a horizon of 10, 20, 30, 40, 50 or 64");
-        if (!(cfg->w_nl[7] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight w_nl[7] must be positive (strict convexity)");
-    } else if (!(cfg->w[6] > 0.0)) return fail(nullptr, MPC_EINVAL, "mpc_create: input weight R*r must be positive (strict convexity)");
-    mpc_handle *h = new (std::nothrow) mpc_handle();
-    if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
-    h->cfg = *cfg;
-    mpc::DevCfg &d = h->dev;
+        if (!mpc::horizon_templated(cfg->N)) return "the NL controller needs a horizon of 10, 20, 30, 40, 50 or 64";
+        if (!(cfg->w_nl[7] > 0.0)) return "input weight w_nl[7] must be positive (strict convexity)";
+    } else if (!(cfg->w[6] > 0.0)) return "input weight R*r must be positive (strict convexity)";
+    if (cfg->solver_layout < MPC_LAYOUT_AUTO || cfg->solver_layout > MPC_LAYOUT_LANE) return "unknown solver_layout";
+    if (cfg->solver_layout == MPC_LAYOUT_LANE && cfg->kind == MPC_KIND_NL) return "the NL controller has no lane-per-scenario kernel";
+    if (!(cfg->max_rate > 0.0) || !(cfg->max_steering > 0.0)) return "max_rate and max_steering must be positive";
+    return nullptr;
+}
+
+static void fill_devcfg(const mpc_config *cfg, mpc::DevCfg &d)
+{
     d.kind = cfg->kind; d.N = cfg->N; d.lpv_lin_prev = cfg->lpv_lin_prev; d.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 80;
     d.dt = cfg->dt; d.eps = cfg->eps; d.max_steering = cfg->max_steering; d.max_rate = cfg->max_rate;
     d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-15; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
     memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);
     memcpy(d.w_nl, cfg->w_nl, sizeof d.w_nl); memcpy(d.we_nl, cfg->we_nl, sizeof d.we_nl);
     d.eps_nl = cfg->eps_nl; d.sqp_tol = cfg->sqp_tol > 0 ? cfg->sqp_tol : 1e-9; d.sqp_max_iter = cfg->sqp_max_iter > 0 ? cfg->sqp_max_iter : 30;
+}
+
+int mpc_create(const mpc_config *cfg, mpc_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, MPC_EINVAL, "mpc_create: null argument");
+    *out = nullptr;
+    if (const char *why = check_config(cfg)) return fail(nullptr, MPC_EINVAL, std::string("mpc_create: ") + why);
+    mpc_handle *h = new (std::nothrow) mpc_handle();
+    if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
+    h->cfg = *cfg;
+    h->lanes = cfg->solver_layout == MPC_LAYOUT_LANE || (cfg->solver_layout == MPC_LAYOUT_AUTO && cfg->kind == MPC_KIND_LPV);
+    fill_devcfg(cfg, h->dev);
     DeviceScope scope(cfg->device);
     hipError_t e = scope.err;
     const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
-    if (e == hipSuccess) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
+    if (e == hipSuccess && !h->lanes) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
+    if (e == hipSuccess && h->lanes) e = hipMalloc(&h->lane_ws, mpc::lanes_workspace_doubles(cfg->N, cfg->B) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
@@ -128,7 +145,7 @@ void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     DeviceScope scope(h->cfg.device);
-    (void)hipFree(h->Hws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
+    (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     (void)hipFree(h->work); (void)hipFree(h->order);
@@ -164,13 +181,19 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
     ON_HANDLE_DEVICE(h);
     if (h->cfg.kind == MPC_KIND_LPV || h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_condense_fixed: the LPV and NL models are re-linearised every step");
     if (!(vx == vx)) { h->sh_on = false; return MPC_OK; }   // NaN switches the cache off
+    if (h->lanes) { h->sh_on = false; return MPC_OK; }      // the lane-per-scenario kernel never condenses: nothing to cache
     // the cache belongs to the register-resident kernels; other horizons keep condensing per scenario (same results)
     if (!mpc::horizon_templated(h->cfg.N)) { h->sh_on = false; return MPC_OK; }
     const size_t N = (size_t)h->cfg.N;
-    if (!h->sh_H) {
-        HIP_TRY(h, hipMalloc(&h->sh_H, N * N * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->sh_Kref, 3 * N * N * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->sh_Kx, 5 * N * sizeof(double)));
+    if (!h->sh_H) {      // all three buffers or none: a partial set would hand the kernels a null pointer on the next call
+        hipError_t e = hipMalloc(&h->sh_H, N * N * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&h->sh_Kref, 3 * N * N * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&h->sh_Kx, 5 * N * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
+            h->sh_H = h->sh_Kref = h->sh_Kx = nullptr; h->sh_on = false;
+            return hip_fail(h, e, "mpc_condense_fixed: cache allocation");
+        }
     }
     HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, (hipStream_t)stream));
     h->sh_vx = vx;
@@ -195,6 +218,7 @@ static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
 static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStream_t st)
 {
     if (h->cfg.kind == MPC_KIND_NL) { a.sqp_out = h->sqp; return mpc::launch_mpc_nl(h->dev, a, st); }
+    if (h->lanes) return mpc::launch_mpc_lanes(h->dev, a, h->lane_ws, (size_t)h->cfg.B, st);
     return mpc::launch_mpc(h->dev, a, st);
 }
 
@@ -212,7 +236,7 @@ static hipError_t launch_chain(mpc_handle *h, const mpc::SolveArgs &a, hipStream
 {
     mpc::SolveArgs c = a;
     const int CHUNK = BAL_CHUNK;
-    if (a.B < BAL_MIN_B) return launch_for_kind(h, c, st);
+    if (a.B < BAL_MIN_B || h->lanes) return launch_for_kind(h, c, st);   // lanes advance in lock step: no order to balance
     int shift = 0;
     const int span = a.nsteps < CHUNK ? a.nsteps : CHUNK;
     while (((span * 24) >> shift) > 1023) shift++;             // up to ~24 iterations per step spread over the 1024 bins
@@ -258,10 +282,10 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
-    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    h->last_B = B;
     HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
@@ -300,10 +324,10 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel; a.step_ramp = h->cfg.step_ramp_length;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
-    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    h->last_B = B;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
@@ -316,6 +340,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     if (int rc = check_batch(h, B, "mpc_ofl_closed_loop_run")) return rc;
     ON_HANDLE_DEVICE(h);
     if (h->cfg.kind != MPC_KIND_OFL) return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: handle is not an OFL controller");
+    if (h->lanes) return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: not available in the lane-per-scenario layout");
     if (nsteps < 1 || !state10 || !ekf_x || !ekf_P || !target_vel || !q_diag_host || !r_diag_host || !u0_out)
         return fail(h, MPC_EINVAL, "mpc_ofl_closed_loop_run: missing argument");
     mpc::SolveArgs a = {};
@@ -324,11 +349,22 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
-    a.status_out = status_out ? status_out : h->status; a.iters_out = iters_out ? iters_out : h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    h->last_iters = a.iters_out; h->last_status = a.status_out; h->last_B = B;
+    h->last_B = B;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
+    return MPC_OK;
+}
+
+int mpc_reset_warm_start(mpc_handle *h, void *stream)
+{
+    if (!h) return MPC_EINVAL;
+    ON_HANDLE_DEVICE(h);
+    // the validity flags of the per-scenario records: one per record (wave layout, at its end) or B packed flags (lane
+    // layout); clearing the whole block covers both
+    if (h->ipm_ws) HIP_TRY(h, hipMemsetAsync(h->ipm_ws, 0, (size_t)h->cfg.B * mpc::IPM_WARM_DOUBLES * sizeof(double), (hipStream_t)stream));
+    h->order_B = 0;
     return MPC_OK;
 }
 
@@ -337,7 +373,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
     if (!h || !host16) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
     ON_HANDLE_DEVICE(h);
-    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->last_iters, h->last_status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->stats16));
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->stats16));
     HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     return MPC_OK;

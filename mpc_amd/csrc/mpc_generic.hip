@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
 #pragma unroll
     for (int q = 0; q < 3; q++) cs[q] = (lane + WAVE * q <= N) ? speed_cumsum(tvel, lane + WAVE * q) : 0.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
-    int iters_tot = 0, status_max = 0, nconstr = 0;
+    int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     double *Hg = a.Hws + (size_t)s * N * N;
     // closed loops start the interior point from the previous step's solve when that step needed one too (record:
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
                 int lp = lapv;
                 p0 = sk_pos2progress(px, py, lp);
                 if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
+                if (lp < 0 || lp > 7) lap_flag = 5;      // the reference switches to its speed profile there (path_planning.py:241-248)
                 prevp = p0;
             } else
                 p0 = px;
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             warm_ok = false;
 
         if (relaxed) status = max(status, 4);
+        status = max(status, lap_flag);
         // ------------------------------------------------------------ 5. outputs, prediction, plant, estimator
 #pragma unroll
         for (int q = 0; q < R; q++)
@@ -853,8 +855,11 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         if (warm_rec) warm_rec[5 * WS] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
         if (a.work_out) a.work_out[s] = iters_tot;
-        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
-        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
+        const int st_all = a.accumulate ? max(a.status_own[s], status_max) : status_max;
+        const int it_all = a.accumulate ? a.iters_own[s] + iters_tot : iters_tot;
+        a.status_own[s] = st_all; a.iters_own[s] = it_all;
+        if (a.status_out) a.status_out[s] = st_all;
+        if (a.iters_out) a.iters_out[s] = it_all;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);

@@ -45,7 +45,8 @@ struct SolveArgs {
     double *Hws;                                          // workspace: B * N * N condensed Hessians
     double *ipm_ws;                                       // workspace: B * IPM_WARM_DOUBLES interior-point warm-start records (or NULL)
     double *U_out, *traj_out, *u0_out, *wp_out;
-    int *status_out, *iters_out;
+    int *status_out, *iters_out;                          // caller's arrays (optional)
+    int *status_own, *iters_own;                          // the handle's own copies (always written; mpc_get_stats reads them)
     int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)
     double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
     // A long closed-loop run is issued as a chain of launches: `order` (a permutation of 0..B-1, or NULL) maps the
@@ -82,6 +83,10 @@ inline hipError_t allow_big_lds(const void *kernel, bool (&done)[MPC_MAX_DEVICES
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
 hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);    // MPC_KIND_NL, horizons of MPC_HORIZONS
 hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);   // run-time horizon, no cache
+// one lane per scenario, stage-wise interior point (kinds L / OFL / LPV, any horizon); ws holds
+// lanes_workspace_doubles(N, Bcap) doubles laid out for a capacity of Bcap scenarios, and keeps the warm-start record between calls
+hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st);
+size_t lanes_workspace_doubles(int N, int B);
 hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
 bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
 bool horizon_templated(int N);    // has a register-resident instantiation (and with it the fixed-model cache)

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
     double *warm_rec = a.ipm_ws ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && a.mode != MODE_SOLVE && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
-    int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0;
+    int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     double *Hw = a.Hws + (size_t)s * N * N;
 
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 int lp = lapv;
                 p0 = sk_pos2progress(px, py, lp);
                 if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
+                if (lp < 0 || lp > 7) lap_flag = 5;      // the reference switches to its speed profile there (path_planning.py:241-248)
                 prevp = p0;
             } else
                 p0 = px;
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             step_prev = step;
         }
         if (relaxed) status_max = max(status_max, 4);
+        status_max = max(status_max, lap_flag);
         sqp_tot += sqp;
         iters_tot += iters;
         status_max = max(status_max, status);
@@ -403,8 +405,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
     if (lane == 0) {
         if (a.u0_out) a.u0_out[s] = u0;
         if (a.work_out) a.work_out[s] = iters_tot;
-        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
-        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
+        const int st_all = a.accumulate ? max(a.status_own[s], status_max) : status_max;
+        const int it_all = a.accumulate ? a.iters_own[s] + iters_tot : iters_tot;
+        a.status_own[s] = st_all; a.iters_own[s] = it_all;
+        if (a.status_out) a.status_out[s] = st_all;
+        if (a.iters_out) a.iters_out[s] = it_all;
         if (a.sqp_out) a.sqp_out[s] = a.accumulate ? a.sqp_out[s] + sqp_tot : sqp_tot;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;

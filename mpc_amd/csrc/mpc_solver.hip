@@ -195,7 +195,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
-    int iters_tot = 0, status_max = 0, nconstr = 0;
+    int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
 
 #pragma unroll 1
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 int lp = lapv;
                 p0 = sk_pos2progress(px, py, lp);
                 if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
+                if (lp < 0 || lp > 7) lap_flag = 5;      // the reference switches to its speed profile there (path_planning.py:241-248)
                 prevp = p0;                                                // path_planning.py:251
             } else
                 p0 = px;                                                   // step_planning.py:83-86
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         } else
             warm_ok = false;
         if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible
+        status = max(status, lap_flag);
 
         // ------------------------------------------------------------ 5. outputs, prediction, plant
         if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;
@@ -431,8 +433,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         if (warm_rec) warm_rec[5 * WAVE] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
         if (a.work_out) a.work_out[s] = iters_tot;
-        if (a.status_out) a.status_out[s] = a.accumulate ? max(a.status_out[s], status_max) : status_max;
-        if (a.iters_out) a.iters_out[s] = a.accumulate ? a.iters_out[s] + iters_tot : iters_tot;
+        const int st_all = a.accumulate ? max(a.status_own[s], status_max) : status_max;
+        const int it_all = a.accumulate ? a.iters_own[s] + iters_tot : iters_tot;
+        a.status_own[s] = st_all; a.iters_own[s] = it_all;
+        if (a.status_out) a.status_out[s] = st_all;
+        if (a.iters_out) a.iters_out[s] = it_all;
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);

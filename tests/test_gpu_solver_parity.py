@@ -196,3 +196,65 @@ def test_lpv_steps_that_once_broke_the_interior_point(orc80, golden):
                                                    float(d["state"][b, 4]), lx, lu)
         assert st == 0
         assert abs(u0[b] - u_ref) <= _tol(np.array([u_ref]))[0], (b, u0[b], u_ref, iters[b])
+
+
+@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("OFL", 80, 0.8), ("L", 7, 0.07), ("L", 128, 1.28)])
+def test_lane_layout_solve_matches_checker(orc80, kind, N, Tf):
+    """The lane-per-scenario kernel (stage-wise Riccati interior point, no condensing) on the L / OFL problems, against
+    the checker: a second GPU algorithm for the same minimiser, next to the condensed wave-per-scenario kernels."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.controllers import LOcp, OFLOcp
+    rng = np.random.default_rng(17)
+    B = 40
+    st = _scenarios(rng, B)
+    st[1] = [15.0, -0.3, 1, 0, 8.0, 0, 0, 0.28]       # steering bound becomes active
+    st[2] = [15.0, 0.3, 1, 0, 8.0, 0, 0, 0.28]
+    st[3] = [12.0, 0.0, 1, 0, 8.0, 0, 0, 0.0]          # on the line: unconstrained
+    st[4] = [15.0, 0.2, 1, 0, 8.0, 0, 0, 0.32]         # start outside the steering bound: status 4 on both sides
+    cfg = O.make_cfg(kind, N, Tf)
+    ctl = (LOcp if kind == "L" else OFLOcp)(N, Tf, batch=B, solver_layout="lane")
+    x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]
+    wps, ps = [], []
+    for s in st:
+        wp, sp, _, _ = orc80.skidpad_waypoints(s[0], s[1], np.arctan2(s[3], s[2]), 0, 0.0, s[4], N, Tf / N)
+        wps.append(wp); ps.append(sp)
+    wps = np.array(wps); ps = np.array(ps)
+    dh = rng.uniform(-12, -8, B) if kind == "OFL" else None
+    U, traj, status, iters = ctl.solve_batched(x0, wps, ps, dh)
+    torch.cuda.synchronize()
+    U = U.cpu().numpy(); traj = traj.cpu().numpy(); status = status.cpu().numpy(); iters = iters.cpu().numpy()
+    nconstrained = 0
+    for b in range(B):
+        stt, traj_ref, U_ref, lam, info = orc80.optimize(cfg, x0[b], wps[b], ps[b], 0.0 if dh is None else dh[b])
+        assert status[b] == stt and stt in (0, 4), (b, status[b], stt)
+        nconstrained += int(np.abs(lam).max() > 1e-9)
+        err = np.abs(U[b] - U_ref)
+        assert (err <= _tol(U_ref)).all(), (b, err.max(), iters[b])
+        np.testing.assert_allclose(traj[b], traj_ref, rtol=1e-7, atol=1e-8)
+    assert nconstrained >= 3
+    if kind == "L" and Tf <= 0.55:
+        assert iters[3] == 0                       # the unconstrained minimiser was taken as it is
+
+
+@pytest.mark.parametrize("model,layout,N,Tf", [("L", "lane", 50, 0.5), ("LPV", "wave", 40, 0.4), ("LPV", "lane", 40, 0.4)])
+def test_closed_loop_in_both_layouts_matches_checker(orc80, model, layout, N, Tf):
+    """40 fused closed-loop steps in the layout that is not the controller's default (L on lanes, LPV on waves), and LPV
+    on lanes at a short horizon, against the checker's loop."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    rng = np.random.default_rng(19)
+    B, nsteps = 24, 40
+    st = _scenarios(rng, B)
+    cfg = O.make_cfg(model, N, Tf)
+    sim = SkidpadBatch(N, Tf, st, model=model, solver_layout=layout)
+    ref_states = st.copy(); laps = np.zeros(B, np.int32); pp = np.zeros(B)
+    uh_ref, _ = orc80.skidpad_run(cfg, ref_states, laps, pp, 8.0, nsteps)
+    xs, us = sim.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    us = us.cpu().numpy()
+    assert (sim.status.cpu().numpy() == 0).all()
+    assert (np.abs(us - uh_ref) <= 10 * _tol(uh_ref)).all(), np.abs(us - uh_ref).max()
+    np.testing.assert_allclose(sim.state.cpu().numpy(), ref_states, rtol=0, atol=1e-7)
+    assert (sim.lap.cpu().numpy() == laps).all()
