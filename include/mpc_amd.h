@@ -136,6 +136,19 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
                    const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out,
                    int *status_out, int *iters_out);
 
+/* mpc_solve_only for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no handle, no workspace argument, no hipMalloc / hipFree inside.  It has no counterpart in
+ * the reference.  The condensed problems live in a static device array of the library (2.1 MB per GPU, held until the
+ * process ends), which limits a call to MPC_NOALLOC_MAX_B scenarios and the horizons 10, 20, 30, 40, 50, 64; more is refused
+ * with MPC_EINVAL.  Kinds L and OFL (cfg->B, the cache and the warm start do not apply: every solve condenses its own
+ * problem and starts cold, so the results equal mpc_solve_only's on a handle without fixed-model cache bit for bit).
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams, two threads) race; issue them
+ * one after the other.  Arguments as mpc_solve_only; errors are read with mpc_last_error(NULL). */
+#define MPC_NOALLOC_MAX_B 64
+#define MPC_NOALLOC_MAX_N 64
+int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const double *x0, const double *wp, const double *p,
+                           const double *d_hat, double *U_out, double *traj_out, int *status_out, int *iters_out);
+
 /* One fused closed-loop step per scenario: plan -> optimize -> RK4 plant -> lap count
  * (SkidpadSimulator.step, skidpad_simulator.py:109-135; StepSimulator.simulate body, simulator.py:178-202).
  *   state [B][8] plant state (updated), lap [B] (updated), prev_progress [B] planner memory (updated),

@@ -368,6 +368,58 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream)
     return MPC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Handle-free solve that allocates nothing: the condensed Hessians and the solver records, which the handle-based entry
+// points keep in the workspace mpc_create allocates, live in a file-scope device array.  Every GPU the library runs on
+// holds its own copy of the array until the process ends; its address on a device is looked up once, with that device
+// current, and only that address (never the array's name, which in host code is a host-side stand-in) goes to kernels.
+constexpr int NOALLOC_MAX_B = MPC_NOALLOC_MAX_B, NOALLOC_MAX_N = MPC_NOALLOC_MAX_N;
+constexpr size_t NOALLOC_H_DOUBLES = (size_t)NOALLOC_MAX_B * NOALLOC_MAX_N * NOALLOC_MAX_N;      // condensed Hessians
+constexpr size_t NOALLOC_STAT_DOUBLES = (size_t)NOALLOC_MAX_B * 4;                               // solver records
+constexpr size_t NOALLOC_INT_DOUBLES = (size_t)NOALLOC_MAX_B;                                    // 2 * MAX_B ints: iterations, status
+constexpr size_t NOALLOC_DOUBLES = NOALLOC_H_DOUBLES + NOALLOC_STAT_DOUBLES + NOALLOC_INT_DOUBLES;
+static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
+static double *g_scratch_ptr[mpc::MPC_MAX_DEVICES] = {};
+
+int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const double *x0, const double *wp, const double *p,
+                           const double *d_hat, double *U_out, double *traj_out, int *status_out, int *iters_out)
+{
+    if (!cfg) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: null configuration");
+    if (const char *why = check_config(cfg)) return fail(nullptr, MPC_EINVAL, std::string("mpc_solve_only_noalloc: ") + why);
+    if (cfg->kind != MPC_KIND_L && cfg->kind != MPC_KIND_OFL)
+        return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: kinds L and OFL only (LPV and NL carry state between calls: use a handle)");
+    if (!mpc::horizon_templated(cfg->N) || cfg->N > NOALLOC_MAX_N)
+        return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: horizon must be 10, 20, 30, 40, 50 or 64");
+    if (B < 1 || B > NOALLOC_MAX_B) {
+        char b[160];
+        snprintf(b, sizeof b, "mpc_solve_only_noalloc: B=%d is outside 1..%d (the static scratch array holds %d condensed problems)", B,
+                 NOALLOC_MAX_B, NOALLOC_MAX_B);
+        return fail(nullptr, MPC_EINVAL, b);
+    }
+    if (!x0 || !wp || !p || !U_out) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: x0, wp, p and U_out are required");
+    if (cfg->device < 0 || cfg->device >= mpc::MPC_MAX_DEVICES) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: device ordinal out of range");
+    DeviceScope scope(cfg->device);
+    if (scope.err != hipSuccess) return hip_fail(nullptr, scope.err, "mpc_solve_only_noalloc: selecting the device");
+    double *base = g_scratch_ptr[cfg->device];
+    if (!base) {                                  // first call on this device: the array's address there
+        hipError_t e = hipGetSymbolAddress((void **)&base, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !base) return hip_fail(nullptr, e, "mpc_solve_only_noalloc: hipGetSymbolAddress(scratch)");
+        g_scratch_ptr[cfg->device] = base;
+    }
+    mpc::DevCfg dev;
+    fill_devcfg(cfg, dev);
+    int *ints = reinterpret_cast<int *>(base + NOALLOC_H_DOUBLES + NOALLOC_STAT_DOUBLES);
+    mpc::SolveArgs a = {};
+    a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat;
+    a.Hws = base;                                 // every scenario's Hessian is written before it is read: nothing to clear
+    a.stat_out = base + NOALLOC_H_DOUBLES;
+    a.iters_own = ints; a.status_own = ints + NOALLOC_MAX_B;
+    a.U_out = U_out; a.traj_out = traj_out; a.status_out = status_out; a.iters_out = iters_out;
+    hipError_t e = mpc::launch_mpc(dev, a, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "mpc_solve_only_noalloc: launch");
+    return MPC_OK;
+}
+
 int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
 {
     if (!h || !host16) return MPC_EINVAL;
