@@ -398,8 +398,9 @@ __device__ __forceinline__ FwdIn load_fwd(const LaneCtxT<LPW> &c, int k, int q)
 }
 
 // one two-sided bound: directions of slacks and multipliers for a move `dv` of the bounded quantity
+struct ProdSums { double s0 = 0.0, s1 = 0.0, s2 = 0.0; };      // sum of (t + a dt)(l + a dl) = s0 + a s1 + a^2 s2, for any a
 __device__ __forceinline__ Con4 bound_dirs(const Con4 &t, const Con4 &aff, double rpp, double rpm, double dv, int mode, double sigmu,
-                                           Ratio &r)
+                                           Ratio &r, ProdSums &ps)
 {
     double rcp = t.tp * t.lp, rcm = t.tm * t.lm;
     if (mode == 1) { rcp += aff.tp * aff.lp - sigmu; rcm += aff.tm * aff.lm - sigmu; }
@@ -411,14 +412,17 @@ __device__ __forceinline__ Con4 bound_dirs(const Con4 &t, const Con4 &aff, doubl
     a.add(t.tp, d.tp); b.add(t.tm, d.tm); a.add(t.lp, d.lp); b.add(t.lm, d.lm);
     a.merge(b);
     r.merge(a);
+    ps.s0 += t.tp * t.lp + t.tm * t.lm;
+    ps.s1 += t.tp * d.lp + t.lp * d.tp + t.tm * d.lm + t.lm * d.tm;
+    ps.s2 += d.tp * d.lp + d.tm * d.lm;
     return d;
 }
 
-// Forward sweep: Newton direction from the stored gains, directions of slacks and multipliers (stored), and the largest
-// step that keeps them positive.  `mode` as in lane_backward (in mode 1 the affine directions are read before they are
+// Forward sweep: Newton direction from the stored gains, directions of slacks and multipliers (stored), the largest step
+// that keeps them positive, and the three sums from which the complementarity after a step of any length follows.  `mode` as in lane_backward (in mode 1 the affine directions are read before they are
 // overwritten); mode 3 writes the inputs of the unconstrained minimiser to LF_U and nothing else.
 template <int LPW, int mode>
-__device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, double sigmu)
+__device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, double sigmu, ProdSums &ps)
 {
     const int N = p.N;
     double dx[6] = {0, 0, 0, 0, 0, 0};
@@ -442,12 +446,12 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
             c.at(LF_U, k) = du;
         else {
             c.at(LF_DU, k) = du;
-            const Con4 d = bound_dirs(f.cu, f.du, f.u + f.cu.tp - p.umax, -f.u + f.cu.tm - p.umax, du, mode, sigmu, r);
+            const Con4 d = bound_dirs(f.cu, f.du, f.u + f.cu.tp - p.umax, -f.u + f.cu.tm - p.umax, du, mode, sigmu, r, ps);
             store4(c, LF_DTPU, k, d);
             if (q < N) {
                 double lo, hi;
                 delta_bounds(p, m.dt, q, lo, hi);
-                const Con4 e = bound_dirs(f.cx, f.dx, f.v + f.cx.tp - hi, -f.v + f.cx.tm + lo, dx[5], mode, sigmu, r);
+                const Con4 e = bound_dirs(f.cx, f.dx, f.v + f.cx.tp - hi, -f.v + f.cx.tm + lo, dx[5], mode, sigmu, r, ps);
                 store4(c, LF_DTPX, q, e);
             }
         }
@@ -585,7 +589,8 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
         // unconstrained minimiser first: it is the minimiser whenever it satisfies every bound.  (After a constrained
         // step the next one is almost always constrained too; the interior point then starts right away.)
         (void)lane_backward<LPW, 3, true>(c, p, m, 0.0);
-        (void)lane_forward<LPW, 3>(c, p, m, 0.0);
+        ProdSums unused;
+        (void)lane_forward<LPW, 3>(c, p, m, 0.0, unused);
         lane_rollout(c, p, m, xh, false);
         if (lane_feasible(c, p, m.dt)) return out;
     }
@@ -670,17 +675,18 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
         }
         mu_last = mu; res_last = res; acc_last = acc; res_prev = res;
         if (!safe) {
-            const double a_aff = lane_forward<LPW, 0>(c, p, m, 0.0);
-            double sum, mn;
-            lane_products(c, p, a_aff, sum, mn);
+            ProdSums ps, ps2;
+            const double a_aff = lane_forward<LPW, 0>(c, p, m, 0.0, ps);
+            const double sum = fmax(ps.s0 + a_aff * (ps.s1 + a_aff * ps.s2), 0.0);       // complementarity after the affine step
             const double sg = (sum / nc2) / mu;
             sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));          // the gap must not outrun the residuals
             (void)lane_backward<LPW, 1, false>(c, p, m, sigmu);
-            alpha = lane_forward<LPW, 1>(c, p, m, sigmu);
+            alpha = lane_forward<LPW, 1>(c, p, m, sigmu, ps2);
             alpha *= fmin(fmax(0.995, 1.0 - mu), 0.999999);                 // never onto the boundary itself
         } else {
             // long-step path following with a neighbourhood of the central path (see interior_point())
-            alpha = lane_forward<LPW, 2>(c, p, m, sigmu);
+            ProdSums ps;
+            alpha = lane_forward<LPW, 2>(c, p, m, sigmu, ps);
             double sum, mn;
             lane_products(c, p, 0.0, sum, mn);
             const double gam = fmin(0.01, 0.5 * mn / mu);

@@ -75,6 +75,9 @@ class Oracle:
                                   _ip, C.c_double, C.c_double, C.c_int]
         L.orc_ofl_run.restype = C.c_long
         L.orc_set_unconstrained_first.argtypes = [C.c_int]
+        L.orc_mpc_optimize_sqp_step.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp,
+                                                C.c_double, C.c_double, C.c_int]
+        L.orc_mpc_optimize_sqp_step.restype = C.c_int
         self.precision = precision
         # default solver tolerances: as tight as the arithmetic allows
         self.tol = (1e-13, 1e-15, 100) if precision == "f64" else (1e-17, 1e-18, 200)
@@ -150,6 +153,18 @@ class Oracle:
                                        _ptr(np.ascontiguousarray(p, dtype=np.float64)), float(d_hat), _ptr(lin_x),
                                        _ptr(lin_u), _ptr(traj), _ptr(U), _ptr(lam), _ptr(info), tol[0], tol[1], tol[2])
         return st, traj, U, lam, info
+
+    def optimize_sqp_step(self, cfg, x0_7, wp, p, x_prev, reg_eps=1e-4, d_hat=0.0, lin_x=None, lin_u=None, tol=(1e-8, 1e-8, 50)):
+        """One SQP iteration of the reference's acados set-up from the iterate x_prev ((N+1,6) states): the QP with the
+        MIRROR-regularised Hessian, solved to HPIPM's default accuracy.  Returns (status, traj, U, x (N+1,6), info)."""
+        N = int(cfg[1])
+        traj = np.zeros((N + 1, 7)); U = np.zeros(N); xo = np.zeros((N + 1, 6)); info = np.zeros(4)
+        st = self.lib.orc_mpc_optimize_sqp_step(_ptr(cfg), _ptr(np.ascontiguousarray(x0_7, dtype=np.float64)),
+                                                _ptr(np.ascontiguousarray(wp, dtype=np.float64)),
+                                                _ptr(np.ascontiguousarray(p, dtype=np.float64)), float(d_hat), _ptr(lin_x),
+                                                _ptr(lin_u), _ptr(np.ascontiguousarray(x_prev, dtype=np.float64)), float(reg_eps),
+                                                _ptr(xo), _ptr(traj), _ptr(U), _ptr(info), tol[0], tol[1], int(tol[2]))
+        return st, traj, U, xo, info
 
     def nl_optimize(self, cfg, x0_7, wp, p, U_warm=None, tol=None):
         """NLOcp.optimize; U_warm is the iterate kept from the previous call (None = zeros).  Returns
@@ -391,3 +406,43 @@ def reconstruct_invariant_set(n, K, A, B, ubx, ubu):
         C_initial = C_initial @ phi
         C = np.concatenate((C, C_initial), axis=0)
     return C
+
+
+# ---------------------------------------------------------------------------
+# acados emulation (study aid; pins nothing: acados itself cannot run here).  What the reference's solver set-up
+# (LMPC2.py:262-288: SQP, EXACT Hessian, regularize_method MIRROR, MERIT_BACKTRACKING, tol 1e-4, iterate kept between
+# calls) returns for the linear-quadratic controllers differs from the unique minimiser of the posed QP because (i) the
+# QP handed to HPIPM carries reg_epsilon on the unweighted states, anchored at the previous iterate, (ii) the SQP loop
+# stops as soon as the KKT residual of the original problem is below 1e-4, (iii) HPIPM stops at about 1e-8.
+# ---------------------------------------------------------------------------
+class AcadosEmulation:
+    """Carries the iterate from call to call like AcadosOcpSolver does; optimize() runs SQP iterations until the
+    stationarity residual the regularisation leaves behind, reg_eps * max|x - x_prev| over the regularised components,
+    is below `tol` (the other KKT residuals of a full step on a linear-quadratic problem are at the QP solver's 1e-8)."""
+
+    def __init__(self, orc: Oracle, cfg, reg_eps: float = 1e-4, tol: float = 1e-4, max_iter: int = 200):
+        self.orc, self.cfg, self.reg_eps, self.tol, self.max_iter = orc, cfg, reg_eps, tol, max_iter
+        N = int(cfg[1])
+        self.x_prev = np.zeros((N + 1, 6))          # acados starts from a zero iterate
+        self.sqp_iterations = []
+
+    def _regularised(self):
+        cfg, dt = self.cfg, self.cfg[2]
+        w_stage = np.abs(dt * cfg[11:17]) < self.reg_eps
+        QN = cfg[18:54].reshape(6, 6)
+        w_term = np.array([not (QN[i].any() or QN[:, i].any()) for i in range(6)])
+        return w_stage, w_term
+
+    def optimize(self, x0_7, wp, p, d_hat=0.0, lin_x=None, lin_u=None):
+        w_stage, w_term = self._regularised()
+        for it in range(1, self.max_iter + 1):
+            st, traj, U, x, info = self.orc.optimize_sqp_step(self.cfg, x0_7, wp, p, self.x_prev, self.reg_eps, d_hat,
+                                                             None if lin_x is None else lin_x.copy(),
+                                                             None if lin_u is None else lin_u.copy())
+            d = np.abs(x - self.x_prev)
+            res = self.reg_eps * max(d[:-1][:, w_stage].max(initial=0.0), d[-1][w_term].max(initial=0.0))
+            self.x_prev = x
+            if res <= self.tol:
+                break
+        self.sqp_iterations.append(it)
+        return st, traj, U
