@@ -44,10 +44,34 @@ enum {
 // Workspace layout: scenarios in blocks of LPW (the lanes of one wave that carry a scenario), and inside a block
 // [stage][field][lane]: every access of a wave is one contiguous run of LPW doubles, and the fields of one stage sit at
 // compile-time offsets from the stage's base address (immediate offsets, no address arithmetic per access).
+// The workspace is addressed through a buffer descriptor per wave (the wave's block of the workspace): an access is
+// descriptor + scalar offset (the stage and a 4 KB window of its fields; the same for every lane, computed by the scalar
+// unit once per stage) + the lane's own byte offset (one vector register for every access of the kernel) + a 12-bit
+// immediate (the field inside the window).  With 64-bit flat addresses the compiler keeps a vector register pair per group
+// of fields and spills them.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 template <int LPW>
 struct LaneCtxT {
-    double *w;            // block base + lane
-    __device__ __forceinline__ double &at(int field, int k) const { return w[((size_t)k * LN_FIELDS + field) * LPW]; }
+    __amdgpu_buffer_rsrc_t rsrc;      // wave-uniform
+    mutable unsigned lane8;           // lane * 8
+    static constexpr unsigned WINDOW = 4096;
+    struct Cell {
+        const LaneCtxT &c; unsigned soff, imm;
+        __device__ __forceinline__ operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(c.rsrc, c.lane8 + imm, soff, 0)); }
+        __device__ __forceinline__ const Cell &operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), c.rsrc, c.lane8 + imm, soff, 0); return *this; }
+        __device__ __forceinline__ const Cell &operator=(const Cell &o) const { return *this = (double)o; }
+    };
+    __device__ __forceinline__ Cell at(int field, int k) const
+    {
+        pin();
+        const unsigned fo = (unsigned)field * (LPW * 8);
+        return Cell{*this, (unsigned)k * (LN_FIELDS * LPW * 8) + fo / WINDOW * WINDOW, fo % WINDOW};
+    }
+    // Makes the lane offset opaque to the optimiser at every access.  "lane offset + field constant" is loop invariant and
+    // common to many accesses: hoisted or shared, it becomes one more vector register (and addition) per field instead of
+    // the immediate of the memory instruction; opaque, the addition stays next to its access and folds.
+    __device__ __forceinline__ void pin() const { asm volatile("" : "+v"(lane8)); }
 };
 
 struct StageM { double e02, e03, e12, e13, f33, f34, f43, f44, c0, c1; };
@@ -160,9 +184,43 @@ __device__ __forceinline__ void delta_bounds(const LaneProb &p, double dt, int k
 // Every sweep below walks the stages with the same shape: everything a stage needs is requested from memory first, then
 // the stage is computed (sched_barrier keeps the compiler from sinking the loads back to their uses), so that a wave
 // waits for memory once per stage, not once per value: left alone the scheduler issues the loads in pairs with a full
-// wait behind each pair.  The light sweeps also request the next stage's values one stage ahead; the heavy ones (Riccati
-// recursion) have no registers to spare for that and rely on the other waves of the SIMD to cover the wait.
+// wait behind each pair.
 #define LANE_LOADS_DONE() __builtin_amdgcn_sched_barrier(0)
+
+// Walks the stages 0..N-1 (FWD) or N-1..0 with the values of a stage requested R - 1 stages before they are used: a
+// round trip to the workspace takes longer than the arithmetic of a light stage, so one stage of lookahead leaves the
+// wave waiting most of the time.  `load(k)` returns what stage k needs, `body(in, k)` computes the stage.  The R buffers
+// The R buffers
+// are used in turn and the loop is unrolled R times, so every buffer has a fixed set of registers and the values just
+// consumed are overwritten by the request for stage k +- (R - 1): no copies.
+template <int R, bool FWD, class In, class Load, class Body>
+__device__ __forceinline__ void lane_sweep(int N, Load load, Body body)
+{
+    In ring[R];
+#pragma unroll
+    for (int d = 0; d < R - 1; d++) ring[d] = load(FWD ? min(d, N - 1) : max(N - 1 - d, 0));
+#pragma unroll 1
+    for (int ib = 0; ib < N; ib += R) {
+#pragma unroll
+        for (int d = 0; d < R; d++) {
+            const int i = ib + d;
+            if (i < N) {
+                const int k = FWD ? i : N - 1 - i;
+                ring[(d + R - 1) % R] = load(FWD ? min(k + R - 1, N - 1) : max(k - (R - 1), 0));
+                LANE_LOADS_DONE();
+                body(ring[d], k);
+                LANE_LOADS_DONE();
+            }
+        }
+    }
+}
+
+#ifndef LN_RING
+#define LN_RING 2
+#endif
+#ifndef LN_RING_HEAVY
+#define LN_RING_HEAVY 2
+#endif
 
 struct Con4 { double tp, tm, lp, lm; };       // slacks and multipliers of one two-sided bound, or their directions
 
@@ -189,22 +247,16 @@ __device__ __forceinline__ void lane_rollout(const LaneCtxT<LPW> &c, const LaneP
     double x[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) { x[i] = xh[i]; c.at(LF_X + i, 0) = xh[i]; }
-    StageM s = load_stage(c, 0);
-    double u = zero_u ? 0.0 : c.at(LF_U, 0);
-#pragma unroll 1
-    for (int k = 0; k < p.N; k++) {
-        const int kn = min(k + 1, p.N - 1);
-        const StageM sn = load_stage(c, kn);
-        const double un = zero_u ? 0.0 : c.at(LF_U, kn);
-        LANE_LOADS_DONE();
-        double y[6];
-        mulA(s, m, x, y);
-        y[0] += s.c0; y[1] += s.c1; y[3] += m.c3; y[5] += m.dt * u;
+    struct In { StageM s; double u; };
+    lane_sweep<LN_RING, true, In>(p.N,
+        [&](int k) { In v; v.s = load_stage(c, k); v.u = zero_u ? 0.0 : c.at(LF_U, k); return v; },
+        [&](const In &v, int k) {
+            double y[6];
+            mulA(v.s, m, x, y);
+            y[0] += v.s.c0; y[1] += v.s.c1; y[3] += m.c3; y[5] += m.dt * v.u;
 #pragma unroll
-        for (int i = 0; i < 6; i++) { x[i] = y[i]; c.at(LF_X + i, k + 1) = y[i]; }
-        LANE_LOADS_DONE();
-        s = sn; u = un;
-    }
+            for (int i = 0; i < 6; i++) { x[i] = y[i]; c.at(LF_X + i, k + 1) = y[i]; }
+        });
 }
 
 // gradient of the terminal cost at x_N
@@ -236,31 +288,21 @@ __device__ __forceinline__ double lane_grad_scale(const LaneCtxT<LPW> &c, const 
 {
     double pi[6], g0 = 0.0;
     terminal_grad(c, p, pi);
-    int k = p.N - 1;
-    StageM s = load_stage(c, k);
-    double x[6], r[3];
-    load6(c, LF_X, k, x);
-    r[0] = c.at(LF_REF, k); r[1] = c.at(LF_REF + 1, k); r[2] = c.at(LF_REF + 2, k);
-#pragma unroll 1
-    for (; k >= 0; k--) {
-        const int kn = max(k - 1, 0);
-        const StageM sn = load_stage(c, kn);
-        double xn[6], rn[3];
-        load6(c, LF_X, kn, xn);
-        rn[0] = c.at(LF_REF, kn); rn[1] = c.at(LF_REF + 1, kn); rn[2] = c.at(LF_REF + 2, kn);
-        LANE_LOADS_DONE();
-        g0 = fmax(g0, fabs(m.dt * pi[5]));
-        double y[6], g[6];
-        mulAt(s, m, pi, y);
-        stage_grad(p, x, r, g);
+    struct In { StageM s; double x[6], r[3]; };
+    lane_sweep<LN_RING, false, In>(p.N,
+        [&](int k) {
+            In v; v.s = load_stage(c, k); load6(c, LF_X, k, v.x);
+            v.r[0] = c.at(LF_REF, k); v.r[1] = c.at(LF_REF + 1, k); v.r[2] = c.at(LF_REF + 2, k);
+            return v;
+        },
+        [&](const In &v, int k) {
+            g0 = fmax(g0, fabs(m.dt * pi[5]));
+            double y[6], g[6];
+            mulAt(v.s, m, pi, y);
+            stage_grad(p, v.x, v.r, g);
 #pragma unroll
-        for (int i = 0; i < 6; i++) pi[i] = g[i] + y[i];
-        LANE_LOADS_DONE();
-        s = sn;
-#pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = xn[i];
-        r[0] = rn[0]; r[1] = rn[1]; r[2] = rn[2];
-    }
+            for (int i = 0; i < 6; i++) pi[i] = g[i] + y[i];
+        });
     return g0;
 }
 
@@ -306,11 +348,7 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
 #pragma unroll
         for (int j = i; j < 6; j++) P(i, j) = p.QN[i * 6 + j];
     }
-    BackIn b = load_back<LPW, mode, factor>(c, N - 1);
-#pragma unroll 1
-    for (int k = N - 1; k >= 0; k--) {
-        const BackIn bn = load_back<LPW, mode, factor>(c, max(k - 1, 0));      // the next stage's values, one stage ahead
-        LANE_LOADS_DONE();
+    lane_sweep<factor ? LN_RING_HEAVY : LN_RING, false, BackIn>(N, [&](int k) { return load_back<LPW, mode, factor>(c, k); }, [&](const BackIn &b, int k) {
         // ---- input constraints of stage k
         double Du = 0.0, wu = 0.0, gu = (mode == 3) ? 0.0 : p.wr * b.u;      // mode 3 starts from u = 0
         if (mode != 3) {
@@ -368,9 +406,7 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
             for (int i = 0; i < 6; i++) pi[i] = gx[i] + y[i];
             if (factor) riccati_matrix_step(P, b.s, m, atpb, ire, p.wq, Dx);
         }
-        LANE_LOADS_DONE();
-        b = bn;
-    }
+    });
     return resd;
 }
 
@@ -381,8 +417,9 @@ struct FwdIn {
     Con4 cu, cx, du, dx;
 };
 template <int LPW, int mode>
-__device__ __forceinline__ FwdIn load_fwd(const LaneCtxT<LPW> &c, int k, int q)
+__device__ __forceinline__ FwdIn load_fwd(const LaneCtxT<LPW> &c, int k, int N)
 {
+    const int q = min(k + 1, N - 1);
     FwdIn f;
     f.s = load_stage(c, k);
     load6(c, LF_ATPB, k, f.atpb);
@@ -427,12 +464,8 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
     const int N = p.N;
     double dx[6] = {0, 0, 0, 0, 0, 0};
     Ratio r;
-    FwdIn f = load_fwd<LPW, mode>(c, 0, 1);
-#pragma unroll 1
-    for (int k = 0; k < N; k++) {
+    lane_sweep<LN_RING, true, FwdIn>(N, [&](int k) { return load_fwd<LPW, mode>(c, k, N); }, [&](const FwdIn &f, int k) {
         const int q = k + 1;
-        const FwdIn fn = load_fwd<LPW, mode>(c, min(k + 1, N - 1), min(k + 2, N - 1));
-        LANE_LOADS_DONE();
         double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; i++) acc = fma(f.atpb[i], dx[i], acc);
@@ -455,9 +488,7 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
                 store4(c, LF_DTPX, q, e);
             }
         }
-        LANE_LOADS_DONE();
-        f = fn;
-    }
+    });
     return r.step();
 }
 
@@ -466,30 +497,32 @@ template <int LPW>
 __device__ __forceinline__ void lane_products(const LaneCtxT<LPW> &c, const LaneProb &p, double alpha, double &sum, double &mn)
 {
     sum = 0.0; mn = 1e300;
-    Con4 tu = load4(c, LF_TPU, 0), du = load4(c, LF_DTPU, 0), tx = load4(c, LF_TPX, 1), dx = load4(c, LF_DTPX, 1);
-#pragma unroll 1
-    for (int k = 0; k < p.N; k++) {
-        const int kn = min(k + 1, p.N - 1), qn = min(k + 2, p.N - 1);
-        const Con4 tun = load4(c, LF_TPU, kn), dun = load4(c, LF_DTPU, kn), txn = load4(c, LF_TPX, qn), dxn = load4(c, LF_DTPX, qn);
-        LANE_LOADS_DONE();
+    struct In { Con4 tu, du, tx, dx; };
+    lane_sweep<LN_RING, true, In>(p.N,
+        [&](int k) {
+            const int q = min(k + 1, p.N - 1);
+            In v; v.tu = load4(c, LF_TPU, k); v.du = load4(c, LF_DTPU, k); v.tx = load4(c, LF_TPX, q); v.dx = load4(c, LF_DTPX, q);
+            return v;
+        },
+        [&](const In &v, int k) {
+        const Con4 &tu = v.tu, &du = v.du, &tx = v.tx, &dx = v.dx;
         const double p1 = (tu.tp + alpha * du.tp) * (tu.lp + alpha * du.lp), p2 = (tu.tm + alpha * du.tm) * (tu.lm + alpha * du.lm);
         sum += p1 + p2; mn = fmin(mn, fmin(p1, p2));
         if (k + 1 < p.N) {
             const double p3 = (tx.tp + alpha * dx.tp) * (tx.lp + alpha * dx.lp), p4 = (tx.tm + alpha * dx.tm) * (tx.lm + alpha * dx.lm);
             sum += p3 + p4; mn = fmin(mn, fmin(p3, p4));
         }
-        LANE_LOADS_DONE();
-        tu = tun; du = dun; tx = txn; dx = dxn;
-    }
+    });
 }
 
-// Takes the step of length alpha along the stored directions (alpha = 0: none), rolls the states out for the new inputs
+// Takes the step of length alpha along the stored directions (`step` false: none), rolls the states out for the new inputs
 // and returns the complementarity (mean product) and the primal residual of the new iterate.  The inputs before the
 // step are kept in LF_UPREV.
 struct StepIn { StageM s; double u, du; Con4 cu, cx, dcu, dcx; };
-template <int LPW>
-__device__ __forceinline__ StepIn load_step(const LaneCtxT<LPW> &c, int k, int q, bool step)
+template <int LPW, bool step>
+__device__ __forceinline__ StepIn load_step(const LaneCtxT<LPW> &c, int k, int N)
 {
+    const int q = min(k + 1, N - 1);
     StepIn v;
     v.s = load_stage(c, k);
     v.u = c.at(LF_U, k);
@@ -497,22 +530,17 @@ __device__ __forceinline__ StepIn load_step(const LaneCtxT<LPW> &c, int k, int q
     if (step) { v.du = c.at(LF_DU, k); v.dcu = load4(c, LF_DTPU, k); v.dcx = load4(c, LF_DTPX, q); }
     return v;
 }
-template <int LPW>
+template <int LPW, bool step>
 __device__ __forceinline__ void lane_step_rollout(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, const double (&xh)[6],
                                                   double alpha, double &mu, double &resp)
 {
     const int N = p.N;
-    const bool step = alpha != 0.0;
     double x[6], musum = 0.0;
     resp = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = xh[i];
-    StepIn v = load_step(c, 0, 1, step);
-#pragma unroll 1
-    for (int k = 0; k < N; k++) {
+    lane_sweep<LN_RING, true, StepIn>(N, [&](int k) { return load_step<LPW, step>(c, k, N); }, [&](const StepIn &v, int k) {
         const int q = k + 1;
-        const StepIn vn = load_step(c, min(k + 1, N - 1), min(k + 2, N - 1), step);
-        LANE_LOADS_DONE();
         double u = v.u;
         Con4 cu = v.cu, cx = v.cx;
         if (step) {
@@ -541,9 +569,7 @@ __device__ __forceinline__ void lane_step_rollout(const LaneCtxT<LPW> &c, const 
             musum += cx.tp * cx.lp + cx.tm * cx.lm;
             resp = fmax(resp, fmax(fabs(x[5] + cx.tp - hi), fabs(-x[5] + cx.tm + lo)));
         }
-        LANE_LOADS_DONE();
-        v = vn;
-    }
+    });
     mu = musum / (2.0 * (2 * N - 1));
 }
 
@@ -552,24 +578,30 @@ template <int LPW>
 __device__ __forceinline__ bool lane_feasible(const LaneCtxT<LPW> &c, const LaneProb &p, double dt)
 {
     bool ok = true;
-    double u = c.at(LF_U, 0), v = c.at(LF_X + 5, 0);
-#pragma unroll 1
-    for (int k = 0; k < p.N; k++) {
-        const int kn = min(k + 1, p.N - 1);
-        const double un = c.at(LF_U, kn), vn = c.at(LF_X + 5, kn);
-        LANE_LOADS_DONE();
-        ok = ok && fabs(u) <= p.umax;
-        if (k >= 1) {
-            double lo, hi;
-            delta_bounds(p, dt, k, lo, hi);
-            ok = ok && v <= hi && v >= lo;
-        }
-        u = un; v = vn;
-    }
+    struct In { double u, v; };
+    lane_sweep<LN_RING, true, In>(p.N, [&](int k) { In v; v.u = c.at(LF_U, k); v.v = c.at(LF_X + 5, k); return v; },
+        [&](const In &v, int k) {
+            ok = ok && fabs(v.u) <= p.umax;
+            if (k >= 1) {
+                double lo, hi;
+                delta_bounds(p, dt, k, lo, hi);
+                ok = ok && v.v <= hi && v.v >= lo;
+            }
+        });
     return ok;
 }
 
 struct LaneResult { int iters, status, constrained; double mu, res; bool warm_valid; };
+
+#ifdef MPC_LANE_TIMING
+// development build: shader-clock cycles per part of the solve, printed by the first wave
+__device__ long long g_lane_t[8];
+#define LT_BEGIN() long long lt0_ = clock64()
+#define LT(i) do { const long long lt1_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_lane_t[i], (unsigned long long)(lt1_ - lt0_)); lt0_ = clock64(); } while (0)
+#else
+#define LT_BEGIN() do { } while (0)
+#define LT(i) do { } while (0)
+#endif
 
 constexpr int LN_SAFE_AFTER = 25;
 
@@ -582,6 +614,7 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
 {
     const int N = p.N;
     LaneResult out = {0, 0, 0, 0.0, 0.0, false};
+    LT_BEGIN();
     // free response and the size of the gradient at u = 0 (scale of the dual residual and of the first multipliers)
     lane_rollout(c, p, m, xh, true);
     const double gscale = fmax(1.0, lane_grad_scale(c, p, m));
@@ -628,22 +661,28 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
         }
     } else
         cold_start();
+    LT(0);
 
     const double nc2 = 2.0 * (2 * N - 1);
     double alpha = 0.0, mu = 0.0, res = 0.0, res_prev = 1e300, mu_last = 0.0, res_last = 0.0;
     bool acc_last = false, rec_ok = true;
     int iters = 0, status = 0;
+    bool fresh = true;              // the iterate was just initialised: no step to take
     for (;;) {
         double resp;
-        lane_step_rollout(c, p, m, xh, alpha, mu, resp);
+        if (fresh) lane_step_rollout<LPW, false>(c, p, m, xh, 0.0, mu, resp);
+        else lane_step_rollout<LPW, true>(c, p, m, xh, alpha, mu, resp);
+        fresh = false;
+        LT(1);
         const bool safe = iters >= LN_SAFE_AFTER;
         double sigmu = safe ? 0.25 * mu : 0.0;
         const double resd = safe ? lane_backward<LPW, 2, true>(c, p, m, sigmu) : lane_backward<LPW, 0, true>(c, p, m, sigmu);
+        LT(2);
         res = fmax(resd / gscale, resp);
         if (warm && iters == 0 && res > IPM_WARM_RES_MAX) {      // the problem moved too far from the previous one
             warm = false;
             cold_start();
-            alpha = 0.0;
+            fresh = true;
             continue;
         }
         // exit rules: see interior_point() in mpc_ipm.hpp
@@ -658,7 +697,7 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
             if (warm && iters < max_iter) {                      // once more from the cold start
                 warm = false;
                 cold_start();
-                alpha = 0.0; res_prev = 1e300; acc_last = false;
+                fresh = true; res_prev = 1e300; acc_last = false;
                 iters++;
                 continue;
             }
@@ -677,11 +716,14 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
         if (!safe) {
             ProdSums ps, ps2;
             const double a_aff = lane_forward<LPW, 0>(c, p, m, 0.0, ps);
+            LT(3);
             const double sum = fmax(ps.s0 + a_aff * (ps.s1 + a_aff * ps.s2), 0.0);       // complementarity after the affine step
             const double sg = (sum / nc2) / mu;
             sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));          // the gap must not outrun the residuals
             (void)lane_backward<LPW, 1, false>(c, p, m, sigmu);
+            LT(4);
             alpha = lane_forward<LPW, 1>(c, p, m, sigmu, ps2);
+            LT(5);
             alpha *= fmin(fmax(0.995, 1.0 - mu), 0.999999);                 // never onto the boundary itself
         } else {
             // long-step path following with a neighbourhood of the central path (see interior_point())
@@ -704,17 +746,18 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
 }
 
 // ------------------------------------------------------------------------------------------------
-// LPW lanes of every wave carry a scenario (the other lanes idle): with few scenarios a smaller LPW spreads them over
-// more waves, and WPB waves per workgroup put several of those on one SIMD, where they hide each other's memory latency.
+// LPW lanes of every wave carry a scenario (the other lanes idle); WPB waves per workgroup (1 in every launch shape in
+// use: workgroups of one wave spread over the compute units first).
 template <int LPW, int WPB>
 __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, const SolveArgs a, double *ws)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int blk = blockIdx.x * WPB + (threadIdx.x >> 6);            // block of LPW scenarios this wave advances
+    const int blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));   // block of LPW scenarios this wave advances
     const int s = blk * LPW + lane;
     if (lane >= LPW || s >= a.B) return;
     const int N = cfg.N;
-    LaneCtxT<LPW> c = {ws + (size_t)blk * (size_t)(N + 1) * LN_FIELDS * LPW + lane};
+    const size_t blk_doubles = (size_t)(N + 1) * LN_FIELDS * LPW;        // < 2^29: checked by the launcher
+    LaneCtxT<LPW> c = {__builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blk * blk_doubles, 0, (int)(blk_doubles * 8), 0x00020000), (unsigned)lane * 8u};
     ModelParams mp;
     if (a.mp_scen) {
         const double *q = a.mp_scen + 6 * (size_t)s;
@@ -851,6 +894,11 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
         for (int i = 0; i < 8; i++) a.state[(size_t)8 * s + i] = plant[i];
         if (a.mode == MODE_SKIDPAD) { a.lap[s] = lapv; a.prev_progress[s] = prevp; }
     }
+#ifdef MPC_LANE_TIMING
+    if (s == 0)
+        printf("lane timing (sum over waves so far, cycles): setup %lld step %lld back0 %lld fwd0 %lld back1 %lld fwd1 %lld\n", g_lane_t[0], g_lane_t[1],
+               g_lane_t[2], g_lane_t[3], g_lane_t[4], g_lane_t[5]);
+#endif
     if (warm_flag) *warm_flag = warm_ok ? 1.0 : 0.0;
     if (a.u0_out) a.u0_out[s] = u0;
     if (a.work_out) a.work_out[s] = iters_tot;
@@ -865,14 +913,17 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     }
 }
 
-// lanes per wave that carry a scenario, by batch size: enough waves to give every SIMD of the chip work first
-// (1024 SIMDs; a wave instruction costs the same time whatever the number of active lanes)
+// Lanes per wave that carry a scenario, by batch size.  A wave runs alone on its compute unit at the rate its own
+// instruction stream issues, whatever the number of active lanes, so full waves are the cheapest as soon as there are
+// scenarios for them; below that, narrower waves lose fewer iterations to the slowest lane of the wave.  (Measured on the
+// LPV workload at N = 80: 64 lanes win from 4096 scenarios up, and two waves on one compute unit already contend for its
+// memory pipeline.)  MPC_LANES_LPW overrides the choice for experiments.
 static int lanes_per_wave(int B)
 {
     static int forced = -1;
     if (forced < 0) { const char *e = getenv("MPC_LANES_LPW"); forced = e ? atoi(e) : 0; }
-    if (forced == 64 || forced == 32 || forced == 16 || forced == 8 || forced == 4) return forced;
-    return B > 32768 ? 64 : B > 16384 ? 32 : 16;
+    if (forced == 64 || forced == 32 || forced == 16 || forced == 8) return forced;
+    return B >= 4096 ? 64 : B >= 2048 ? 16 : 8;
 }
 
 size_t lanes_workspace_doubles(int N, int B)
@@ -894,12 +945,12 @@ static hipError_t launch_lanes_t(const DevCfg &cfg, const SolveArgs &a, double *
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st)
 {
     if (cfg.kind == MPC_KIND_NL || a.mode == MODE_OFL || !ws) return hipErrorInvalidValue;
+    if ((size_t)(cfg.N + 1) * LN_FIELDS * 64 * 8 >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // a wave's block must fit a 32-bit byte offset
     switch (lanes_per_wave((int)Bcap)) {
-    case 64: return launch_lanes_t<64, 4>(cfg, a, ws, st);
-    case 32: return launch_lanes_t<32, 4>(cfg, a, ws, st);
-    case 16: return launch_lanes_t<16, 4>(cfg, a, ws, st);
-    case 4: return launch_lanes_t<4, 8>(cfg, a, ws, st);
-    default: return launch_lanes_t<8, 4>(cfg, a, ws, st);
+    case 64: return launch_lanes_t<64, 1>(cfg, a, ws, st);
+    case 32: return launch_lanes_t<32, 1>(cfg, a, ws, st);
+    case 16: return launch_lanes_t<16, 1>(cfg, a, ws, st);
+    default: return launch_lanes_t<8, 1>(cfg, a, ws, st);
     }
 }
 

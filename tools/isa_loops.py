@@ -20,5 +20,5 @@ for h in [i for i, l in enumerate(lines) if "Inner Loop Header" in l]:
     if e is None: continue
     body = lines[h:e]
     cnt = lambda pat: sum(bool(re.search(pat, l)) for l in body)
-    print(f"{label:12s} len {e - h:4d} scratch {cnt('scratch_load'):3d}/{cnt('scratch_store'):3d} global {cnt('global_load'):3d}/{cnt('global_store'):3d} "
+    print(f"{label:12s} len {e - h:4d} scratch {cnt('scratch_load'):3d}/{cnt('scratch_store'):3d} global {cnt('global_load|buffer_load'):3d}/{cnt('global_store|buffer_store'):3d} "
           f"lds {cnt(r'ds_read|ds_write'):3d} fp64 {cnt(r'v_fma|v_mul_f64|v_add_f64|v_fmac'):4d} mov {cnt(r'v_mov|v_accvgpr'):3d} waits {cnt('s_waitcnt vmcnt'):2d}")
