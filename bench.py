@@ -56,16 +56,18 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
     an affine map of the step's data, `ncomp` weighted reference components (2 with the yaml's weights: the x weight is
     zero) + 5 state terms: 2(ncomp N^2 + 5N); bound check 10N; RK4 400; c4 adds the EKF (two 10x10x10 products, 7x7
     solve with 10 right-hand sides, gain products) ~ 8000.
-    c3 (condensed per scenario and step): stage model 130N; prediction columns and gradient 16N^2; Hessian, 3 weighted
-    outputs, N^3 + 6N^2; LDL' N^3/3 + 2N^2.
+    c3 (stage-wise Riccati interior point, nothing condensed), per stage of the horizon: stage model 130; free response,
+    gradient scale and warm start ~60, plus ~400 on the steps that try the unconstrained minimiser first (taken as
+    300 on average); per interior-point iteration ~880 (step and roll-out 75, Riccati matrix and vector recursion with
+    the barrier terms 400, affine forward sweep 120, corrector backward sweep 150, corrector forward sweep 130).
     c5, per SQP iteration: RK4 roll-out 160N; RK4 derivative 700N; prediction columns 52N^2/2; Hessian, 5 weighted
     outputs, 5N^3/3; gradient and H*U 4N^2; LDL' N^3/3 + 2N^2.
-    Every interior-point iteration adds ipm_flops(N)."""
+    Every interior-point iteration of c2/c4/c5 adds ipm_flops(N)."""
     plan = 60 * (N + 1) + 400
     if workload in ("c2", "c4"):
         fixed = plan + 2 * (ncomp * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)
     elif workload == "c3":
-        fixed = plan + 130 * N + 16 * N * N + N ** 3 + 6 * N * N + N ** 3 / 3 + 2 * N * N
+        return plan + N * (130 + 300 + 880 * mean_iters)
     else:
         fixed = plan + mean_sqp * (860 * N + 26 * N * N + 5 * N ** 3 / 3 + 4 * N * N + N ** 3 / 3 + 2 * N * N)
     return fixed + ipm_flops(N) * mean_iters
@@ -84,6 +86,16 @@ def algorithmic_bytes(workload: str, N: int) -> float:
     covariance and 7 noise samples, c5 the input iterate N.  (The condensed Hessian scratch is method traffic.)"""
     extra = {"c2": 0, "c3": 6 * (N + 1) + N, "c4": 2 + 10 + 100 + 7, "c5": N}[workload]
     return (8 + 3 + 1 + extra) * 8 * 2
+
+
+def method_bytes(workload: str, N: int, mean_iters: float) -> float | None:
+    """Workspace bytes the lane-per-scenario kernel streams per scenario-step (c3; the other kernels keep their problem in
+    registers and LDS): per stage and interior-point iteration its five sweeps read or write 206 doubles (step 44,
+    Riccati 36, affine forward 37, corrector backward 44, corrector forward 45); set-up of a step (stage model and
+    references written, free response, gradient scale, warm start or the unconstrained attempt) about 70."""
+    if workload != "c3":
+        return None
+    return 8.0 * N * (70 + 206 * mean_iters)
 
 
 def host_threads() -> int:
@@ -147,13 +159,15 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
 
 
 def measured_traffic(args):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this process); only
-    for the configuration those passes were taken on, else None."""
-    path = os.path.join(ROOT, "profiles", "r01e_c2_fused_hbm_traffic.json")
-    if args.workload != "c2" or args.per_step_launch or args.steps != 1000 or args.batch not in (None, 4096) or not os.path.exists(path):
+    """HBM bytes per launch of the timed region from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
+    this process); only for a configuration those passes were taken on, else None."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if args.per_step_launch or not os.path.exists(path):
         return None
     with open(path) as fh:
-        return json.load(fh)["hbm_bytes_per_launch"]
+        table = json.load(fh)
+    key = f"{args.workload}:B={args.batch or WORKLOADS[args.workload]['B']}:steps={args.steps}:warmup={args.warmup}"
+    return table.get(key, {}).get("hbm_bytes_per_launch")
 
 
 WORKLOADS = {
@@ -420,17 +434,27 @@ def main() -> None:
                        "max_residual": maxima["max_residual"],
                        "transient_scenario_steps_per_s": (B * world * args.warmup / t_warm) if args.warmup else None,
                        "steady_state": steady},
-            "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": measured_traffic(args),
-                         "kernel": wl["kernel"], "avg_launch_ms": launch_s * 1e3,
-                         "scenario_steps_per_launch": B * steps_per_launch,
-                         "algorithmic_flops_per_scenario_step": flops,
-                         "note": "FP64 vector/matrix peak; the kernels are latency- and issue-bound, not FP64-throughput-bound",
-                         "hbm": {"achieved_GBs": algorithmic_bytes(args.workload, N) * B * steps_per_launch / launch_s / 1e9,
-                                 "peak_GBs": PEAK_HBM_GBS}},
         }
+        fp64 = {"achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_TFLOPS,
+                "algorithmic_flops_per_scenario_step": flops}
+        common = {"traffic": measured_traffic(args), "kernel": wl["kernel"], "avg_launch_ms": launch_s * 1e3,
+                  "scenario_steps_per_launch": B * steps_per_launch}
+        mbytes = method_bytes(args.workload, N, mean_iters)
+        if mbytes is not None:
+            # the lane-per-scenario kernel streams its stage-wise workspace from HBM in every sweep: HBM is its nearer roof
+            ach = mbytes * B * steps_per_launch / launch_s / 1e9
+            out["roofline"] = dict({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS},
+                                   **common, algorithmic_bytes_per_scenario_step=mbytes, fp64=fp64,
+                                   note="workspace streaming of the stage-wise interior point (method bytes); a wave also runs at the "
+                                        "issue rate of its own instruction stream, see DESIGN.md")
+        else:
+            out["roofline"] = dict({"bound": "mfma"}, **fp64, **common,
+                                   note="FP64 vector/matrix peak; the kernels are latency- and issue-bound, not FP64-throughput-bound",
+                                   hbm={"achieved_GBs": algorithmic_bytes(args.workload, N) * B * steps_per_launch / launch_s / 1e9,
+                                        "peak_GBs": PEAK_HBM_GBS})
         if world == 1 and not args.no_cpu_baseline:
-            sample = {"c2": (1024, 300), "c3": (256, 40), "c4": (512, 100), "c5": (512, 20)}[args.workload]
+            # sized for 10-30 s of host work each
+            sample = {"c2": (4096, 500), "c3": (2048, 400), "c4": (2048, 300), "c5": (4096, 100)}[args.workload]
             out["cpu_baseline"] = cpu_baseline(args.workload, *sample)
         print(json.dumps(out))
     if world > 1:

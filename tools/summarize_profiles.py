@@ -12,6 +12,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 tag = sys.argv[3] if len(sys.argv) > 3 else "r01b"
 os.makedirs(dst, exist_ok=True)
+traffic = {}
 for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
     name = os.path.basename(os.path.dirname(db))
     con = sqlite3.connect(db)
@@ -35,4 +36,25 @@ for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
             w.writerow(["kernel", "counter", "dispatches", "sum", "avg_per_dispatch"])
             for r in q[:12]:
                 w.writerow([r[0][:120], r[1], int(r[2]), r[3], r[4]])
+    if pmc and name.startswith("pmc"):
+        # HBM bytes of the timed launch: the MPC kernel dispatches in order are [settling launch (c2 only)], warm-up,
+        # timed region, ...; FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950 tallies reads at half their size
+        kind, wl = name[3], name[5:]
+        disp = con.execute("select dispatch_id, sum(value), max(duration) from counters_collection where kernel_name like '%k_mpc%' "
+                           "group by dispatch_id order by dispatch_id").fetchall()
+        idx = 2 if wl == "c2_driver" else 1
+        if len(disp) > idx:
+            traffic.setdefault(wl, {})["fetch_bytes" if kind == "f" else "write_bytes"] = disp[idx][1] * 1024 * (2 if kind == "f" else 1)
+            traffic[wl]["launch_ns_under_counters"] = disp[idx][2]
     print(name, "kernels:", [(r[0][:40], r[1], round(r[3])) for r in rows[:3]], "pmc rows", pmc)
+
+if traffic:
+    import json
+    keys = {"c2_driver": "c2:B=4096:steps=20:warmup=5", "c2_default": "c2:B=4096:steps=1000:warmup=50", "c3": "c3:B=8192:steps=100:warmup=10"}
+    out = {}
+    for wl, t in traffic.items():
+        if "fetch_bytes" in t and "write_bytes" in t:
+            out[keys.get(wl, wl)] = dict(t, hbm_bytes_per_launch=t["fetch_bytes"] + t["write_bytes"])
+    with open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(out)
