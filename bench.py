@@ -454,7 +454,7 @@ def main() -> None:
                                         "peak_GBs": PEAK_HBM_GBS})
         if world == 1 and not args.no_cpu_baseline:
             # sized for 10-30 s of host work each
-            sample = {"c2": (4096, 500), "c3": (2048, 400), "c4": (2048, 300), "c5": (4096, 100)}[args.workload]
+            sample = {"c2": (4096, 1000), "c3": (2048, 400), "c4": (2048, 300), "c5": (4096, 100)}[args.workload]
             out["cpu_baseline"] = cpu_baseline(args.workload, *sample)
         print(json.dumps(out))
     if world > 1:

@@ -1,6 +1,7 @@
 """Terminal-set helpers with the function names of the reference's stability.py.  The vertex test of
 check_control_amissible_invariance runs on the GPU for whole batches of level values; the LP loop of
-estimate_control_amissible_invariant_set (cvxpy / ECOS in the reference, stability.py:7-90) is not reproduced."""
+estimate_control_amissible_invariant_set (cvxpy / ECOS in the reference, stability.py:7-90) is set-up arithmetic on the
+host, as in the reference, with scipy's LP solver in place of ECOS."""
 from __future__ import annotations
 
 import numpy as np
@@ -48,6 +49,55 @@ def reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu, save_path=
     if save_path is not None:
         np.save(save_path, Cm)
     return Cm
+
+
+def estimate_control_amissible_invariant_set(K, A, B, ubx, ubu, verbose=False, n_limit=1000, save_path=None):
+    """stability.py:7-90.  Grows the set { x : |phi^k x| <= ubx, |K phi^k x| <= ubu, k = 1..n-1 } (phi = A - B K) one power
+    at a time; after each step 2 (len(ubx) + len(ubu)) linear programmes maximise the components of phi^n x / ubx and
+    K phi^n x / ubu (both signs) over the set, and the loop ends when every optimum is below 5e-2 (the reference's test)
+    or n exceeds `n_limit`; the rows are then rebuilt by reconstruct_control_amissible_invariant_set(n, ...).
+    Kept as the reference has them: the first power constrained is phi^1, not phi^0 (x itself is never bounded); an
+    unbounded programme counts as +inf and keeps the loop going.  Where the reference catches cvxpy's SolverError and
+    skips the rest of that group of programmes, a programme HiGHS cannot finish is skipped the same way.  The optimum
+    of each programme is HiGHS's instead of ECOS's (interior point, ~1e-8): the stopping index n can differ by one step
+    where an optimum sits within solver tolerance of 5e-2.  Returns the row matrix C (C x <= 1)."""
+    from scipy.optimize import linprog
+    K = np.atleast_2d(np.asarray(K, dtype=np.float64)); A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
+    ubx = np.asarray(ubx, dtype=np.float64).reshape(-1); ubu = np.asarray(ubu, dtype=np.float64).reshape(-1)
+    phi = A - B @ K
+    phi_np1 = phi.copy()
+    rows, rhs = [], []
+    n = 1
+
+    def maximise(c):
+        r = linprog(-c, A_ub=np.concatenate(rows), b_ub=np.concatenate(rhs), bounds=(None, None), method="highs")
+        if r.status == 0:
+            return float(-r.fun)
+        if r.status == 3:
+            return float("inf")
+        raise RuntimeError(r.message)
+
+    while True:
+        M = phi_np1
+        rows += [M, -M, K @ M, -(K @ M)]
+        rhs += [ubx, ubx, ubu, ubu]
+        n += 1
+        phi_np1 = phi_np1 @ phi
+        opt_values = []
+        groups = [[phi_np1[j] / ubx[j] for j in range(len(ubx))], [(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))],
+                  [-phi_np1[j] / ubx[j] for j in range(len(ubx))], [-(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))]]
+        for group in groups:
+            try:
+                for c in group:
+                    opt_values.append(maximise(c))
+            except RuntimeError as e:
+                if verbose:
+                    print(f"n = {n}: programme not solved ({e}); rest of its group skipped")
+        if verbose:
+            print(f"n = {n}: optima {opt_values}")
+        if np.all(np.array(opt_values) < 5e-2) or n > n_limit:
+            return reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu, save_path=save_path)
 
 
 def _eigh(P):
