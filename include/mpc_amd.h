@@ -48,6 +48,8 @@ extern "C" {
 
 #define MPC_MAX_HORIZON 128
 
+#define MPC_MAX_TERMINAL_ROWS 256
+
 #define MPC_LAYOUT_AUTO 0
 #define MPC_LAYOUT_WAVE 1
 #define MPC_LAYOUT_LANE 2
@@ -241,6 +243,17 @@ int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const doubl
  * ok_out [nc] (device) receives 1 where no image leaves the box, else 0. */
 int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, const double *eig_host, const double *A_host,
                          const double *B_host, const double *K_host, double umax, const double *c, int *ok_out);
+
+/* Terminal set of the linear controllers (L, OFL, LPV):  C (x_N[1:] - x_ref) <= 1  on the last predicted state, over
+ * (py, psi, vy, r, delta), x_ref = (y_ref, sin psi_ref, 0, 0, 0) of the last reference point (zero for the LPV controller,
+ * like its terminal cost reference).  This is the constraint the reference prepares and leaves commented out
+ * (LMPC2.py:212-218: con_h_expr_e = C (x[1:] - x_ref), uh_e = 1, lh_e = -1e7; C from
+ * stability.py:93-112 reconstruct_control_amissible_invariant_set).  C_host: m rows of 5 doubles, host memory, copied;
+ * m = 0 removes the set.  General rows are handled by the stage-wise solver only: the handle must have been created
+ * with solver_layout = MPC_LAYOUT_LANE (MPC_EINVAL otherwise).  Synchronises the device, resizes the handle's workspace
+ * and forgets the warm-start records.  A problem whose terminal set cannot be reached within the input bounds has no
+ * minimiser: such solves end with status 2. */
+int mpc_set_terminal_set(mpc_handle *h, int m, const double *C_host);
 
 /* Forgets the interior-point warm-start records and the scenario order learnt from earlier launches: the next solve of
  * every scenario starts cold.  No counterpart in the reference (acados keeps its iterate inside the solver object and the

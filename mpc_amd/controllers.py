@@ -78,7 +78,7 @@ class _CondensedMpc:
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
                  ipm_warm_start: bool = True, step_ramp_length: float = 0.0, solver_layout: str = "auto",
-                 _host_only: bool = False):
+                 terminal_set=None, _host_only: bool = False):
         if not discrete:
             raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
@@ -107,12 +107,16 @@ class _CondensedMpc:
         # "wave": one wavefront per scenario on the condensed problem; "lane": one lane per scenario, stage-wise Riccati
         # interior point; "auto": lane for the LPV controller, wave otherwise
         self._layout = _lib.LAYOUT[solver_layout]
+        if terminal_set is not None and solver_layout == "auto":
+            self._layout = _lib.LAYOUT["lane"]          # general terminal rows are handled by the stage-wise solver
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
             self.device = None
             self.solver = None
         else:
             self.device = _dev.require_gpu(device)
             self.solver = SolverHandle(self._make_config())
+            if terminal_set is not None:
+                self.set_terminal_set(terminal_set)
         self.metrics = {"runtime": []}
         self._bufs = {}
 
@@ -173,7 +177,9 @@ class _CondensedMpc:
     def stability(self):
         """DARE terminal weight exactly as LMPC2.py:349-440 poses it: forward-Euler (A,B) at vx=15 cast to
         float32, px dropped, Q' = diag(W11, W22, 0, 0, W33), R' = W[4,4].  The control-admissible set the
-        reference also estimates there (stability.py) never enters the OCP and is not computed."""
+        reference also estimates there (LMPC2.py:444-449, stability.py:7-90) never enters its OCP (the terminal
+        constraint is commented out, LMPC2.py:212-218); here it is computed on first use of `terminal_set_estimate()`
+        and enters the problem only through `set_terminal_set` / the constructor's `terminal_set`."""
         A = (np.eye(6) + self.dt * self.continuous_A(float(self.p_lin_point[0]))).astype(np.float32)
         B = np.zeros((6, 1)); B[5, 0] = self.dt
         B = B.astype(np.float32)
@@ -186,6 +192,26 @@ class _CondensedMpc:
         self.P = scipy.linalg.solve_discrete_are(Ad, Bd, Q, R)
         self.K = np.linalg.solve(Bd.T @ self.P @ Bd + R, Bd.T @ self.P @ Ad)
         self.C = None
+
+    def terminal_set_estimate(self):
+        """The rows `self.C` of LMPC2.py:444-449: estimate_control_amissible_invariant_set(K, A, B, ubx, ubu) with
+        ubx = (100, 100, 100, 100, max_steering), ubu = (max_steering_rate); computed once, on the host."""
+        if self.C is None:
+            from .stability import estimate_control_amissible_invariant_set
+            ubx = np.array([100, 100, 100, 100, self.max_steering], dtype=np.float64)
+            ubu = np.array([self.max_steering_rate], dtype=np.float64)
+            self.C = estimate_control_amissible_invariant_set(self.K, self.A_stability.astype(np.float64),
+                                                              self.B_stability.astype(np.float64), ubx, ubu)
+        return self.C
+
+    def set_terminal_set(self, C):
+        """Adds the terminal constraint C (x_N[1:] - x_ref) <= 1 the reference leaves commented out (LMPC2.py:212-218) to
+        every following solve; C (m, 5) over (py, psi, vy, r, delta), None removes it.  Needs solver_layout "lane"."""
+        C = np.zeros((0, 5)) if C is None else np.ascontiguousarray(C, dtype=np.float64)
+        if C.ndim != 2 or C.shape[1] != 5:
+            raise ValueError("terminal set: rows of 5 coefficients over (py, psi, vy, r, delta)")
+        rc = self.solver._lib.mpc_set_terminal_set(self.solver.h, int(C.shape[0]), _lib.hptr(C))
+        _lib.check(rc, self.solver.h, "mpc_set_terminal_set")
 
     # ---- per step -----------------------------------------------------------------------------
     def waypoints_to_references(self, waypoints: np.ndarray) -> np.ndarray:

@@ -20,6 +20,8 @@ struct mpc_handle {
     int order_B = 0;                           // batch size `order` is a permutation for (0: none yet)
     double *mp_scen = nullptr;   // optional B * 6
     double *cost_scen = nullptr; // optional B * 43 per-scenario cost weights
+    double *term_C = nullptr;    // optional terminal set rows [term_m][5] (lane layout)
+    int term_m = 0;
     double *stats16 = nullptr;   // device result of the statistics reduction
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double sh_vx = 0.0;
@@ -119,7 +121,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     hipError_t e = scope.err;
     const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
     if (e == hipSuccess && !h->lanes) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
-    if (e == hipSuccess && h->lanes) e = hipMalloc(&h->lane_ws, mpc::lanes_workspace_doubles(cfg->N, cfg->B) * sizeof(double));
+    if (e == hipSuccess && h->lanes) e = hipMalloc(&h->lane_ws, mpc::lanes_workspace_doubles(cfg->N, cfg->B, 0) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
@@ -145,7 +147,7 @@ void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     DeviceScope scope(h->cfg.device);
-    (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
+    (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
     (void)hipFree(h->work); (void)hipFree(h->order);
@@ -172,6 +174,36 @@ int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario)
     const size_t bytes = (size_t)h->cfg.B * 43 * sizeof(double);
     if (!h->cost_scen) HIP_TRY(h, hipMalloc(&h->cost_scen, bytes));
     HIP_TRY(h, hipMemcpy(h->cost_scen, cost_per_scenario, bytes, hipMemcpyDeviceToDevice));
+    return MPC_OK;
+}
+
+int mpc_set_terminal_set(mpc_handle *h, int m, const double *C_host)
+{
+    if (!h) return MPC_EINVAL;
+    ON_HANDLE_DEVICE(h);
+    if (m < 0 || m > MPC_MAX_TERMINAL_ROWS || (m > 0 && !C_host)) return fail(h, MPC_EINVAL, "mpc_set_terminal_set: 0 <= m <= MPC_MAX_TERMINAL_ROWS rows of 5 doubles");
+    if (m > 0 && !h->lanes)
+        return fail(h, MPC_EINVAL, "mpc_set_terminal_set: general terminal rows are solved stage-wise; create the controller with solver_layout = MPC_LAYOUT_LANE");
+    if (m > 0 && h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_set_terminal_set: linear controllers only");
+    if (!h->lanes) return MPC_OK;                          // m == 0 on a wave-layout handle: nothing to remove
+    HIP_TRY(h, hipDeviceSynchronize());                    // the workspace changes shape: no launch of this handle may be in flight
+    // rows, then a workspace with room for their slacks and multipliers; on failure the handle keeps what it had
+    double *C_new = nullptr, *ws_new = nullptr;
+    if (m > 0) {
+        hipError_t e = hipMalloc(&C_new, (size_t)m * 5 * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(C_new, C_host, (size_t)m * 5 * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(C_new); return hip_fail(h, e, "mpc_set_terminal_set: rows"); }
+    }
+    if (m != h->term_m) {
+        hipError_t e = hipMalloc(&ws_new, mpc::lanes_workspace_doubles(h->cfg.N, h->cfg.B, m) * sizeof(double));
+        if (e != hipSuccess) { (void)hipFree(C_new); return hip_fail(h, e, "mpc_set_terminal_set: workspace"); }
+        (void)hipFree(h->lane_ws);
+        h->lane_ws = ws_new;
+    }
+    (void)hipFree(h->term_C);
+    h->term_C = C_new; h->term_m = m;
+    // the records of earlier solves belong to another problem (and another workspace shape)
+    if (h->ipm_ws) HIP_TRY(h, hipMemset(h->ipm_ws, 0, (size_t)h->cfg.B * mpc::IPM_WARM_DOUBLES * sizeof(double)));
     return MPC_OK;
 }
 
@@ -282,7 +314,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;
@@ -324,7 +356,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel; a.step_ramp = h->cfg.step_ramp_length;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;
@@ -349,7 +381,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;

@@ -64,6 +64,9 @@ struct SolveArgs {
     double sh_vx;
     int sh_exclusive;        // caller promises every scenario runs at sh_vx: launch the fixed-model-only kernel
     int sh_mask;             // bit c set: reference component c (x, y, sin psi) carries weight
+    // Terminal set C (x_N[1:] - x_ref) <= 1 (lane-per-scenario layout only): rows [term_m][5] in device memory, 0 = none.
+    int term_m;
+    const double *term_C;
 };
 
 // Raises a kernel's dynamic-LDS limit to the CU's 160 KB once per device and kernel (`done` is that kernel's flag table).
@@ -86,7 +89,7 @@ hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 // one lane per scenario, stage-wise interior point (kinds L / OFL / LPV, any horizon); ws holds
 // lanes_workspace_doubles(N, Bcap) doubles laid out for a capacity of Bcap scenarios, and keeps the warm-start record between calls
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st);
-size_t lanes_workspace_doubles(int N, int B);
+size_t lanes_workspace_doubles(int N, int B, int term_m);
 hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
 bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
 bool horizon_templated(int N);    // has a register-resident instantiation (and with it the fixed-model cache)

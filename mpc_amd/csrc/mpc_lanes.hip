@@ -41,9 +41,12 @@ enum {
     LN_FIELDS = 46
 };
 
+enum { TF_T = 0, TF_L, TF_DT, TF_DL };      // per terminal row: slack, multiplier, their directions
+
 // Workspace layout: scenarios in blocks of LPW (the lanes of one wave that carry a scenario), and inside a block
 // [stage][field][lane]: every access of a wave is one contiguous run of LPW doubles, and the fields of one stage sit at
-// compile-time offsets from the stage's base address (immediate offsets, no address arithmetic per access).
+// compile-time offsets from the stage's base address (immediate offsets, no address arithmetic per access).  After the
+// stages of a block: [terminal row][TF_*][lane] when a terminal set is in use.
 // The workspace is addressed through a buffer descriptor per wave (the wave's block of the workspace): an access is
 // descriptor + scalar offset (the stage and a 4 KB window of its fields; the same for every lane, computed by the scalar
 // unit once per stage) + the lane's own byte offset (one vector register for every access of the kernel) + a 12-bit
@@ -55,6 +58,7 @@ template <int LPW>
 struct LaneCtxT {
     __amdgpu_buffer_rsrc_t rsrc;      // wave-uniform
     mutable unsigned lane8;           // lane * 8
+    unsigned tbase;                   // byte offset of the terminal-row block (after the N + 1 stages)
     static constexpr unsigned WINDOW = 4096;
     struct Cell {
         const LaneCtxT &c; unsigned soff, imm;
@@ -68,11 +72,30 @@ struct LaneCtxT {
         const unsigned fo = (unsigned)field * (LPW * 8);
         return Cell{*this, (unsigned)k * (LN_FIELDS * LPW * 8) + fo / WINDOW * WINDOW, fo % WINDOW};
     }
+    // slack, multiplier and their directions (f = TF_T..TF_DL) of terminal row i
+    __device__ __forceinline__ Cell term(int f, int i) const
+    {
+        pin();
+        return Cell{*this, tbase + (unsigned)(i * 4 + f) * (LPW * 8), 0u};
+    }
+    // The same workspace with this lane switched off unless `on`: its offset lies outside the descriptor's range, so the
+    // hardware drops its stores and its loads return zero, with no change of EXEC.  The solver's control flow is uniform
+    // per wave; lanes that are done, or take another path, run along switched off and their results are discarded by
+    // selects.  (Divergent regions around whole sweeps made the compiler park live registers in AGPRs inside the region,
+    // ahead of the EXEC restore of the join: lanes that skipped the region got stale values back.)
+    __device__ __forceinline__ LaneCtxT masked(bool on) const
+    {
+        LaneCtxT r = *this;
+        r.lane8 = on ? lane8 : 0x80000000u;
+        return r;
+    }
     // Makes the lane offset opaque to the optimiser at every access.  "lane offset + field constant" is loop invariant and
     // common to many accesses: hoisted or shared, it becomes one more vector register (and addition) per field instead of
     // the immediate of the memory instruction; opaque, the addition stays next to its access and folds.
     __device__ __forceinline__ void pin() const { asm volatile("" : "+v"(lane8)); }
 };
+
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
 struct StageM { double e02, e03, e12, e13, f33, f34, f43, f44, c0, c1; };
 struct ScenM { double dt, f35, f45, c3; };     // parts of the model that do not change over the horizon
@@ -170,7 +193,23 @@ struct LaneProb {
     double umax, dmax, d0;         // d0: steering angle at the start of the horizon
     double xr_term_zero;           // 1: the terminal reference is zero (LPV), 0: the planner's
     int N;
+    int mT;                        // rows of the terminal set  CT (x_N[1:] - x_ref) <= 1  (0: none)
+    const double *CT;              // [mT][5], the same for every scenario (wave-uniform: scalar loads)
 };
+
+// x_N[1:] - x_ref of the terminal set, x_ref = (y_ref, sin psi_ref, 0, 0, 0) of the last stage (zero where the terminal
+// cost reference is), from the states in the workspace or from `xN` when given
+template <int LPW>
+__device__ __forceinline__ void term_error(const LaneCtxT<LPW> &c, const LaneProb &p, const double *xN, double (&e)[5])
+{
+#pragma unroll
+    for (int j = 0; j < 5; j++) e[j] = xN ? xN[1 + j] : (double)c.at(LF_X + 1 + j, p.N);
+    if (p.xr_term_zero == 0.0) { e[0] -= c.at(LF_REF + 1, p.N); e[1] -= c.at(LF_REF + 2, p.N); }
+}
+__device__ __forceinline__ double term_dot(const double *cr, const double (&e)[5])
+{
+    return cr[0] * e[0] + cr[1] * e[1] + cr[2] * e[2] + cr[3] * e[3] + cr[4] * e[4];
+}
 
 __device__ __forceinline__ void delta_bounds(const LaneProb &p, double dt, int k, double &lo, double &hi)
 {
@@ -348,6 +387,30 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
 #pragma unroll
         for (int j = i; j < 6; j++) P(i, j) = p.QN[i * 6 + j];
     }
+    if (mode != 3 && p.mT > 0) {
+        // terminal rows: multipliers into both adjoints, the Newton right-hand side and (factor) the barrier Hessian
+        double e[5];
+        term_error(c, p, nullptr, e);
+#pragma unroll 1
+        for (int i = 0; i < p.mT; i++) {
+            const double *cr = p.CT + 5 * i;
+            const double t = c.term(TF_T, i), l = c.term(TF_L, i);
+            double rc = t * l;
+            if (mode == 1) rc += (double)c.term(TF_DT, i) * (double)c.term(TF_DL, i) - sigmu; else if (mode == 2) rc -= sigmu;
+            const double rp = term_dot(cr, e) + t - 1.0;
+            const double it = fast_rcp(t);
+            const double w = (l * rp - rc) * it, D = l * it;
+#pragma unroll
+            for (int a = 0; a < 5; a++) {
+                pi[1 + a] += l * cr[a];
+                pv[1 + a] += (l + w) * cr[a];
+                if (factor) {
+#pragma unroll
+                    for (int b = a; b < 5; b++) P(1 + a, 1 + b) += D * cr[a] * cr[b];
+                }
+            }
+        }
+    }
     lane_sweep<factor ? LN_RING_HEAVY : LN_RING, false, BackIn>(N, [&](int k) { return load_back<LPW, mode, factor>(c, k); }, [&](const BackIn &b, int k) {
         // ---- input constraints of stage k
         double Du = 0.0, wu = 0.0, gu = (mode == 3) ? 0.0 : p.wr * b.u;      // mode 3 starts from u = 0
@@ -489,6 +552,23 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
             }
         }
     });
+    if (mode != 3 && p.mT > 0) {
+        double e[5];
+        term_error(c, p, nullptr, e);
+        const double dxe[5] = {dx[1], dx[2], dx[3], dx[4], dx[5]};
+#pragma unroll 1
+        for (int i = 0; i < p.mT; i++) {
+            const double *cr = p.CT + 5 * i;
+            const double t = c.term(TF_T, i), l = c.term(TF_L, i);
+            double rc = t * l;
+            if (mode == 1) rc += (double)c.term(TF_DT, i) * (double)c.term(TF_DL, i) - sigmu; else if (mode == 2) rc -= sigmu;
+            const double d_t = -(term_dot(cr, e) + t - 1.0) - term_dot(cr, dxe);
+            const double d_l = -(rc + l * d_t) * fast_rcp(t);
+            r.add(t, d_t); r.add(l, d_l);
+            ps.s0 += t * l; ps.s1 += t * d_l + l * d_t; ps.s2 += d_t * d_l;
+            c.term(TF_DT, i) = d_t; c.term(TF_DL, i) = d_l;
+        }
+    }
     return r.step();
 }
 
@@ -513,15 +593,21 @@ __device__ __forceinline__ void lane_products(const LaneCtxT<LPW> &c, const Lane
             sum += p3 + p4; mn = fmin(mn, fmin(p3, p4));
         }
     });
+#pragma unroll 1
+    for (int i = 0; i < p.mT; i++) {
+        const double pr = ((double)c.term(TF_T, i) + alpha * (double)c.term(TF_DT, i)) * ((double)c.term(TF_L, i) + alpha * (double)c.term(TF_DL, i));
+        sum += pr; mn = fmin(mn, pr);
+    }
 }
 
-// Takes the step of length alpha along the stored directions (`step` false: none), rolls the states out for the new inputs
+// Takes the step of length alpha along the stored directions (a fresh iterate has zero directions), rolls the states out for the new inputs
 // and returns the complementarity (mean product) and the primal residual of the new iterate.  The inputs before the
 // step are kept in LF_UPREV.
 struct StepIn { StageM s; double u, du; Con4 cu, cx, dcu, dcx; };
-template <int LPW, bool step>
+template <int LPW>
 __device__ __forceinline__ StepIn load_step(const LaneCtxT<LPW> &c, int k, int N)
 {
+    constexpr bool step = true;
     const int q = min(k + 1, N - 1);
     StepIn v;
     v.s = load_stage(c, k);
@@ -530,16 +616,17 @@ __device__ __forceinline__ StepIn load_step(const LaneCtxT<LPW> &c, int k, int N
     if (step) { v.du = c.at(LF_DU, k); v.dcu = load4(c, LF_DTPU, k); v.dcx = load4(c, LF_DTPX, q); }
     return v;
 }
-template <int LPW, bool step>
+template <int LPW>
 __device__ __forceinline__ void lane_step_rollout(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, const double (&xh)[6],
                                                   double alpha, double &mu, double &resp)
 {
     const int N = p.N;
+    constexpr bool step = true;
     double x[6], musum = 0.0;
     resp = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = xh[i];
-    lane_sweep<LN_RING, true, StepIn>(N, [&](int k) { return load_step<LPW, step>(c, k, N); }, [&](const StepIn &v, int k) {
+    lane_sweep<LN_RING, true, StepIn>(N, [&](int k) { return load_step(c, k, N); }, [&](const StepIn &v, int k) {
         const int q = k + 1;
         double u = v.u;
         Con4 cu = v.cu, cx = v.cx;
@@ -570,7 +657,21 @@ __device__ __forceinline__ void lane_step_rollout(const LaneCtxT<LPW> &c, const 
             resp = fmax(resp, fmax(fabs(x[5] + cx.tp - hi), fabs(-x[5] + cx.tm + lo)));
         }
     });
-    mu = musum / (2.0 * (2 * N - 1));
+    if (p.mT > 0) {
+        double e[5];
+        term_error(c, p, x, e);
+#pragma unroll 1
+        for (int i = 0; i < p.mT; i++) {
+            double t = c.term(TF_T, i), l = c.term(TF_L, i);
+            if (step) {
+                t = fma(alpha, (double)c.term(TF_DT, i), t); l = fma(alpha, (double)c.term(TF_DL, i), l);
+                c.term(TF_T, i) = t; c.term(TF_L, i) = l;
+            }
+            musum += t * l;
+            resp = fmax(resp, fabs(term_dot(p.CT + 5 * i, e) + t - 1.0));
+        }
+    }
+    mu = musum / (2.0 * (2 * N - 1) + p.mT);
 }
 
 // true when the inputs in the workspace and their predicted steering angles satisfy every bound
@@ -588,6 +689,12 @@ __device__ __forceinline__ bool lane_feasible(const LaneCtxT<LPW> &c, const Lane
                 ok = ok && v.v <= hi && v.v >= lo;
             }
         });
+    if (p.mT > 0) {
+        double e[5];
+        term_error(c, p, nullptr, e);
+#pragma unroll 1
+        for (int i = 0; i < p.mT; i++) ok = ok && term_dot(p.CT + 5 * i, e) <= 1.0;
+    }
     return ok;
 }
 
@@ -605,9 +712,56 @@ __device__ long long g_lane_t[8];
 
 constexpr int LN_SAFE_AFTER = 25;
 
+// Starting point of the interior point on the lanes of `c` that are switched on: with `warm` (per lane) the inputs and
+// multipliers that the previous closed-loop step left in the workspace, moved one stage ahead, slacks pushed back to a
+// small distance from the bounds (as interior_point() does); otherwise u = 0, slacks at the distance of the bounds,
+// multipliers lam0.  The directions are zeroed, so that the first pass of the step sweep leaves the iterate as it is.
+template <int LPW>
+__device__ __forceinline__ void lane_init_iterate(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, bool warm, double lam0, double gscale)
+{
+    const int N = p.N;
+    const double delta = 3e-3, mu0 = delta * 0.01 * gscale;
+    double dl = p.d0;
+#pragma unroll 1
+    for (int k = 0; k < N; k++) {
+        const int kn = (k < N - 1) ? k + 1 : k;                              // the record one stage ahead
+        const double uw = fmin(fmax((double)c.at(LF_U, kn), -p.umax), p.umax);
+        const double a0 = c.at(LF_LPU, kn), a1 = c.at(LF_LMU, kn), a2 = c.at(LF_LPX, kn), a3 = c.at(LF_LMX, kn);
+        LANE_LOADS_DONE();
+        const double u = warm ? uw : 0.0;
+        const double tpu = warm ? fmax(p.umax - u, delta * 2.0 * p.umax) : p.umax, tmu = warm ? fmax(p.umax + u, delta * 2.0 * p.umax) : p.umax;
+        double lo, hi;
+        delta_bounds(p, m.dt, k, lo, hi);
+        const double tpx = warm ? fmax(hi - dl, delta * 2.0 * p.dmax) : fmax(hi - p.d0, 0.1 * p.dmax);
+        const double tmx = warm ? fmax(dl - lo, delta * 2.0 * p.dmax) : fmax(p.d0 - lo, 0.1 * p.dmax);
+        c.at(LF_U, k) = u;
+        c.at(LF_TPU, k) = tpu; c.at(LF_TMU, k) = tmu;
+        c.at(LF_LPU, k) = warm ? fmax(a0, mu0 / tpu) : lam0; c.at(LF_LMU, k) = warm ? fmax(a1, mu0 / tmu) : lam0;
+        c.at(LF_TPX, k) = tpx; c.at(LF_TMX, k) = tmx;
+        c.at(LF_LPX, k) = warm ? fmax(a2, mu0 / tpx) : lam0; c.at(LF_LMX, k) = warm ? fmax(a3, mu0 / tmx) : lam0;
+        c.at(LF_DU, k) = 0.0;
+        store4(c, LF_DTPU, k, Con4{0.0, 0.0, 0.0, 0.0});
+        store4(c, LF_DTPX, k, Con4{0.0, 0.0, 0.0, 0.0});
+        dl = fma(m.dt, u, dl);                                               // steering angle of stage k + 1
+        LANE_LOADS_DONE();
+    }
+    if (p.mT > 0) {
+        double e[5];
+        term_error(c, p, nullptr, e);           // of whatever roll-out the workspace holds: only a starting size
+#pragma unroll 1
+        for (int i = 0; i < p.mT; i++) {        // terminal rows stay with the last stage: nothing to move
+            const double tw = fmax((double)c.term(TF_T, i), delta * 2.0), lw = c.term(TF_L, i);
+            const double t = warm ? tw : fmax(1.0 - term_dot(p.CT + 5 * i, e), 0.1);
+            c.term(TF_T, i) = t; c.term(TF_L, i) = warm ? fmax(lw, mu0 / t) : lam0;
+            c.term(TF_DT, i) = 0.0; c.term(TF_DL, i) = 0.0;
+        }
+    }
+}
+
 // One solve.  Stage model and references of the step must be in the workspace; `warm` says that the workspace still
-// holds inputs and multipliers of a constrained solve of the previous closed-loop step (they are then moved one stage
-// ahead and used as the starting point, as interior_point() does).
+// holds inputs and multipliers of a constrained solve of the previous closed-loop step.
+// Control flow is uniform over the wave: every branch that contains a sweep is taken when any lane needs it, with the
+// other lanes switched off through their workspace context, and the per-lane decisions are selects.
 template <int LPW>
 __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const LaneProb &p, const ScenM &m, const double (&xh)[6],
                                                  bool warm, double tol_mu, double tol_res, int max_iter)
@@ -618,128 +772,108 @@ __device__ __forceinline__ LaneResult lane_solve(const LaneCtxT<LPW> &c, const L
     // free response and the size of the gradient at u = 0 (scale of the dual residual and of the first multipliers)
     lane_rollout(c, p, m, xh, true);
     const double gscale = fmax(1.0, lane_grad_scale(c, p, m));
-    if (!warm) {
+    bool active = true;                     // the lane still iterates
+    if (wave_any(!warm)) {
         // unconstrained minimiser first: it is the minimiser whenever it satisfies every bound.  (After a constrained
         // step the next one is almost always constrained too; the interior point then starts right away.)
-        (void)lane_backward<LPW, 3, true>(c, p, m, 0.0);
+        const LaneCtxT<LPW> cc = c.masked(!warm);
+        (void)lane_backward<LPW, 3, true>(cc, p, m, 0.0);
         ProdSums unused;
-        (void)lane_forward<LPW, 3>(c, p, m, 0.0, unused);
-        lane_rollout(c, p, m, xh, false);
-        if (lane_feasible(c, p, m.dt)) return out;
+        (void)lane_forward<LPW, 3>(cc, p, m, 0.0, unused);
+        lane_rollout(cc, p, m, xh, false);
+        const bool feasible = lane_feasible(cc, p, m.dt);
+        active = warm || !feasible;
     }
-    out.constrained = 1;
+    out.constrained = active ? 1 : 0;
     const double lam0 = fmax(1.0, 0.01 * gscale);
-    auto cold_start = [&]() {
-        for (int k = 0; k < N; k++) {
-            double lo, hi;
-            delta_bounds(p, m.dt, k, lo, hi);
-            c.at(LF_U, k) = 0.0;
-            c.at(LF_TPU, k) = p.umax; c.at(LF_TMU, k) = p.umax; c.at(LF_LPU, k) = lam0; c.at(LF_LMU, k) = lam0;
-            c.at(LF_TPX, k) = fmax(hi - p.d0, 0.1 * p.dmax); c.at(LF_TMX, k) = fmax(p.d0 - lo, 0.1 * p.dmax);
-            c.at(LF_LPX, k) = lam0; c.at(LF_LMX, k) = lam0;
-        }
-    };
-    if (warm) {
-        const double delta = 3e-3, mu0 = delta * 0.01 * gscale;
-        double dl = p.d0;
-        for (int k = 0; k < N; k++) {
-            const int ku = (k < N - 1) ? k + 1 : k, kx = (k < N - 1) ? k + 1 : k;      // the record one stage ahead
-            const double u = fmin(fmax(c.at(LF_U, ku), -p.umax), p.umax);
-            const double a0 = c.at(LF_LPU, ku), a1 = c.at(LF_LMU, ku), a2 = c.at(LF_LPX, kx), a3 = c.at(LF_LMX, kx);
-            c.at(LF_U, k) = u;
-            const double tpu = fmax(p.umax - u, delta * 2.0 * p.umax), tmu = fmax(p.umax + u, delta * 2.0 * p.umax);
-            c.at(LF_TPU, k) = tpu; c.at(LF_TMU, k) = tmu;
-            c.at(LF_LPU, k) = fmax(a0, mu0 / tpu); c.at(LF_LMU, k) = fmax(a1, mu0 / tmu);
-            if (k >= 1) {
-                double lo, hi;
-                delta_bounds(p, m.dt, k, lo, hi);
-                const double tpx = fmax(hi - dl, delta * 2.0 * p.dmax), tmx = fmax(dl - lo, delta * 2.0 * p.dmax);
-                c.at(LF_TPX, k) = tpx; c.at(LF_TMX, k) = tmx;
-                c.at(LF_LPX, k) = fmax(a2, mu0 / tpx); c.at(LF_LMX, k) = fmax(a3, mu0 / tmx);
-            }
-            dl = fma(m.dt, u, dl);              // steering angle of stage k + 1
-        }
-    } else
-        cold_start();
+    if (wave_any(active)) lane_init_iterate(c.masked(active), p, m, warm, lam0, gscale);
     LT(0);
 
-    const double nc2 = 2.0 * (2 * N - 1);
+    const double nc2 = 2.0 * (2 * N - 1) + p.mT;
     double alpha = 0.0, mu = 0.0, res = 0.0, res_prev = 1e300, mu_last = 0.0, res_last = 0.0;
     bool acc_last = false, rec_ok = true;
     int iters = 0, status = 0;
-    bool fresh = true;              // the iterate was just initialised: no step to take
-    for (;;) {
-        double resp;
-        if (fresh) lane_step_rollout<LPW, false>(c, p, m, xh, 0.0, mu, resp);
-        else lane_step_rollout<LPW, true>(c, p, m, xh, alpha, mu, resp);
-        fresh = false;
+    while (wave_any(active)) {
+        const LaneCtxT<LPW> ca = c.masked(active);
+        double mu_n, resp;
+        lane_step_rollout(ca, p, m, xh, alpha, mu_n, resp);
         LT(1);
         const bool safe = iters >= LN_SAFE_AFTER;
-        double sigmu = safe ? 0.25 * mu : 0.0;
-        const double resd = safe ? lane_backward<LPW, 2, true>(c, p, m, sigmu) : lane_backward<LPW, 0, true>(c, p, m, sigmu);
-        LT(2);
-        res = fmax(resd / gscale, resp);
-        if (warm && iters == 0 && res > IPM_WARM_RES_MAX) {      // the problem moved too far from the previous one
-            warm = false;
-            cold_start();
-            fresh = true;
-            continue;
+        const double sigmu_s = 0.25 * mu_n;
+        double resd = 0.0;
+        if (wave_any(active && !safe)) resd = lane_backward<LPW, 0, true>(c.masked(active && !safe), p, m, 0.0);
+        if (wave_any(active && safe)) {
+            const double r2 = lane_backward<LPW, 2, true>(c.masked(active && safe), p, m, sigmu_s);
+            resd = safe ? r2 : resd;
         }
+        LT(2);
+        const double res_n = fmax(resd / gscale, resp);
+        mu = active ? mu_n : mu; res = active ? res_n : res;
         // exit rules: see interior_point() in mpc_ipm.hpp
+        const bool reject = active && warm && iters == 0 && res > IPM_WARM_RES_MAX;      // the problem moved too far from the previous one
+        const bool live = active && !reject;
         const bool finite = fabs(mu) < 1e300 && fabs(res) < 1e300;
         const bool acc = finite && mu <= 10.0 * tol_mu && res <= 1e3 * tol_res;
-        bool restore = false;
-        if (acc_last && !acc) { restore = true; rec_ok = false; }
-        else if (finite && mu <= tol_mu && res <= tol_res) break;
-        else if (acc && (res >= 0.5 * res_prev || mu <= 1e-3 * tol_mu)) break;
-        else if (!finite || mu <= 1e-3 * tol_mu || iters >= max_iter) {
-            if (acc) break;
-            if (warm && iters < max_iter) {                      // once more from the cold start
-                warm = false;
-                cold_start();
-                fresh = true; res_prev = 1e300; acc_last = false;
-                iters++;
-                continue;
-            }
-            restore = !finite && iters > 0;
-            rec_ok = false; status = 2;
+        const bool worse = live && acc_last && !acc;                                      // back to the last acceptable iterate
+        const bool rest = live && !worse;
+        const bool done = rest && ((finite && mu <= tol_mu && res <= tol_res) || (acc && (res >= 0.5 * res_prev || mu <= 1e-3 * tol_mu)));
+        const bool stuck = rest && !done && (!finite || mu <= 1e-3 * tol_mu || iters >= max_iter);
+        const bool done2 = stuck && acc;
+        const bool restart = stuck && !acc && warm && iters < max_iter;                   // once more from the cold start
+        const bool failed = stuck && !acc && !restart;
+        const bool restore = worse || (failed && !finite && iters > 0);
+        rec_ok = rec_ok && !worse && !failed;
+        status = failed ? 2 : status;
+        if (wave_any(restore)) {
+            const LaneCtxT<LPW> cr = c.masked(restore);
+#pragma unroll 1
+            for (int k = 0; k < N; k++) cr.at(LF_U, k) = cr.at(LF_UPREV, k);
+            lane_rollout(cr, p, m, xh, false);
         }
-        if (restore || status) {
-            if (restore) {
-                for (int k = 0; k < N; k++) c.at(LF_U, k) = c.at(LF_UPREV, k);
-                lane_rollout(c, p, m, xh, false);
-                mu = mu_last; res = res_last;
-            }
-            break;
-        }
-        mu_last = mu; res_last = res; acc_last = acc; res_prev = res;
-        if (!safe) {
+        mu = restore ? mu_last : mu; res = restore ? res_last : res;
+        const bool again = reject || restart;                                             // cold start, no iteration counted for a rejected warm start
+        if (wave_any(again)) lane_init_iterate(c.masked(again), p, m, false, lam0, gscale);
+        warm = warm && !again;
+        iters += restart ? 1 : 0;
+        res_prev = restart ? 1e300 : res_prev; acc_last = restart ? false : acc_last;
+        active = active && !(worse || done || done2 || failed);
+        const bool go = active && !again;                                                 // lanes that compute a step in this pass
+        mu_last = go ? mu : mu_last; res_last = go ? res : res_last; acc_last = go ? acc : acc_last; res_prev = go ? res : res_prev;
+        double alpha_n = 0.0;
+        if (wave_any(go && !safe)) {
+            const LaneCtxT<LPW> cn = c.masked(go && !safe);
             ProdSums ps, ps2;
-            const double a_aff = lane_forward<LPW, 0>(c, p, m, 0.0, ps);
+            const double a_aff = lane_forward<LPW, 0>(cn, p, m, 0.0, ps);
             LT(3);
             const double sum = fmax(ps.s0 + a_aff * (ps.s1 + a_aff * ps.s2), 0.0);       // complementarity after the affine step
             const double sg = (sum / nc2) / mu;
-            sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));          // the gap must not outrun the residuals
-            (void)lane_backward<LPW, 1, false>(c, p, m, sigmu);
+            const double sigmu = fmax(sg * sg * sg * mu, 1e-3 * fmin(mu, res));           // the gap must not outrun the residuals
+            (void)lane_backward<LPW, 1, false>(cn, p, m, sigmu);
             LT(4);
-            alpha = lane_forward<LPW, 1>(c, p, m, sigmu, ps2);
+            alpha_n = lane_forward<LPW, 1>(cn, p, m, sigmu, ps2);
             LT(5);
-            alpha *= fmin(fmax(0.995, 1.0 - mu), 0.999999);                 // never onto the boundary itself
-        } else {
-            // long-step path following with a neighbourhood of the central path (see interior_point())
-            ProdSums ps;
-            alpha = lane_forward<LPW, 2>(c, p, m, sigmu, ps);
-            double sum, mn;
-            lane_products(c, p, 0.0, sum, mn);
-            const double gam = fmin(0.01, 0.5 * mn / mu);
-            alpha *= 0.99;
-            for (int bt = 0; bt < 20; bt++) {
-                lane_products(c, p, alpha, sum, mn);
-                if (mn >= gam * sum / nc2) break;
-                alpha *= 0.6;
-            }
+            alpha_n *= fmin(fmax(0.995, 1.0 - mu), 0.999999);                             // never onto the boundary itself
         }
-        iters++;
+        if (wave_any(go && safe)) {
+            // long-step path following with a neighbourhood of the central path (see interior_point())
+            const bool on = go && safe;
+            const LaneCtxT<LPW> cs = c.masked(on);
+            ProdSums ps;
+            double a_s = lane_forward<LPW, 2>(cs, p, m, sigmu_s, ps);
+            double sum, mn;
+            lane_products(cs, p, 0.0, sum, mn);
+            const double gam = fmin(0.01, 0.5 * mn / mu);
+            a_s *= 0.99;
+            bool cut = on;
+            for (int bt = 0; bt < 20 && wave_any(cut); bt++) {
+                lane_products(c.masked(cut), p, a_s, sum, mn);
+                cut = cut && !(mn >= gam * sum / nc2);
+                a_s = cut ? 0.6 * a_s : a_s;
+            }
+            alpha_n = safe ? a_s : alpha_n;
+        }
+        alpha = go ? alpha_n : 0.0;
+        iters += go ? 1 : 0;
     }
     out.iters = iters; out.status = status; out.mu = mu; out.res = res; out.warm_valid = rec_ok && status == 0;
     return out;
@@ -756,8 +890,10 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     const int s = blk * LPW + lane;
     if (lane >= LPW || s >= a.B) return;
     const int N = cfg.N;
-    const size_t blk_doubles = (size_t)(N + 1) * LN_FIELDS * LPW;        // < 2^29: checked by the launcher
-    LaneCtxT<LPW> c = {__builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blk * blk_doubles, 0, (int)(blk_doubles * 8), 0x00020000), (unsigned)lane * 8u};
+    const size_t stage_doubles = (size_t)(N + 1) * LN_FIELDS * LPW;
+    const size_t blk_doubles = stage_doubles + (size_t)4 * a.term_m * LPW;      // < 2^28: checked by the launcher
+    LaneCtxT<LPW> c = {__builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blk * blk_doubles, 0, (int)(blk_doubles * 8), 0x00020000), (unsigned)lane * 8u,
+                       (unsigned)(stage_doubles * 8)};
     ModelParams mp;
     if (a.mp_scen) {
         const double *q = a.mp_scen + 6 * (size_t)s;
@@ -768,6 +904,7 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     LaneProb p;
     p.N = N; p.umax = cfg.max_rate; p.dmax = cfg.max_steering;
     p.xr_term_zero = (cfg.kind == MPC_KIND_LPV) ? 1.0 : 0.0;     // LPVMPC.py:220-221: the terminal reference stays zero
+    p.mT = a.term_m; p.CT = a.term_C;
 #pragma unroll
     for (int i = 0; i < 6; i++) p.wq[i] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + i] : cfg.w[i]);   // acados scales stage costs by dt
     p.wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
@@ -926,10 +1063,10 @@ static int lanes_per_wave(int B)
     return B >= 4096 ? 64 : B >= 2048 ? 16 : 8;
 }
 
-size_t lanes_workspace_doubles(int N, int B)
+size_t lanes_workspace_doubles(int N, int B, int term_m)
 {
     const size_t lpw = (size_t)lanes_per_wave(B);
-    return ((size_t)B + lpw - 1) / lpw * lpw * (size_t)LN_FIELDS * (size_t)(N + 1);
+    return ((size_t)B + lpw - 1) / lpw * lpw * ((size_t)LN_FIELDS * (size_t)(N + 1) + (size_t)4 * term_m);
 }
 
 template <int LPW, int WPB>
@@ -945,7 +1082,8 @@ static hipError_t launch_lanes_t(const DevCfg &cfg, const SolveArgs &a, double *
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st)
 {
     if (cfg.kind == MPC_KIND_NL || a.mode == MODE_OFL || !ws) return hipErrorInvalidValue;
-    if ((size_t)(cfg.N + 1) * LN_FIELDS * 64 * 8 >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // a wave's block must fit a 32-bit byte offset
+    if (((size_t)(cfg.N + 1) * LN_FIELDS + (size_t)4 * a.term_m) * 64 * 8 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // a wave's block must fit a 32-bit byte offset
+    if (a.term_m < 0 || (a.term_m > 0 && !a.term_C)) return hipErrorInvalidValue;
     switch (lanes_per_wave((int)Bcap)) {
     case 64: return launch_lanes_t<64, 1>(cfg, a, ws, st);
     case 32: return launch_lanes_t<32, 1>(cfg, a, ws, st);

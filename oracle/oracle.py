@@ -75,6 +75,8 @@ class Oracle:
                                   _ip, C.c_double, C.c_double, C.c_int]
         L.orc_ofl_run.restype = C.c_long
         L.orc_set_unconstrained_first.argtypes = [C.c_int]
+        L.orc_set_terminal_set.argtypes = [C.c_int, _dp]
+        L.orc_set_terminal_set.restype = C.c_int
         L.orc_mpc_optimize_sqp_step.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp,
                                                 C.c_double, C.c_double, C.c_int]
         L.orc_mpc_optimize_sqp_step.restype = C.c_int
@@ -215,6 +217,14 @@ class Oracle:
                                      status.ctypes.data_as(_ip), tol[0], tol[1], tol[2])
         return uh, xh, eh, status, int(iters)
 
+    def set_terminal_set(self, C=None):
+        """Terminal set C (x_N[1:] - x_ref) <= 1 for every following solve of the linear controllers (LMPC2.py:212-218,
+        commented out in the reference); None or an empty array removes it."""
+        C = np.zeros((0, 5)) if C is None else np.ascontiguousarray(C, dtype=np.float64)
+        assert C.ndim == 2 and C.shape[1] == 5
+        if self.lib.orc_set_terminal_set(int(C.shape[0]), _ptr(C)) != 0:
+            raise ValueError("too many terminal rows")
+
     def set_unconstrained_first(self, on: bool):
         """Timed CPU baseline only: try the unconstrained minimiser (one Riccati pass) before the interior point."""
         self.lib.orc_set_unconstrained_first(int(bool(on)))
@@ -327,8 +337,9 @@ def make_cfg(kind: str, N: int, Tf: float, params: dict | None = None, orc: Orac
 # ---------------------------------------------------------------------------
 # dense KKT certificate of the condensed QP (numpy; independent of the C solver)
 # ---------------------------------------------------------------------------
-def condensed_qp(cfg, x0_7, wp, p, d_hat=0.0):
-    """Dense (H, g, A, lo, up) of the L/OFL problem built by explicit prediction matrices."""
+def condensed_qp(cfg, x0_7, wp, p, d_hat=0.0, terminal_C=None):
+    """Dense (H, g, A, lo, up) of the L/OFL problem built by explicit prediction matrices; with `terminal_C` (m x 5) the
+    rows C (x_N[1:] - x_ref) <= 1 are appended (lower bound -inf)."""
     kind, N, dt = int(cfg[0]), int(cfg[1]), cfg[2]
     assert kind in (0, 1)
     mp = cfg[3:9]
@@ -353,6 +364,11 @@ def condensed_qp(cfg, x0_7, wp, p, d_hat=0.0):
     A = np.vstack([np.eye(N), T])
     lo = np.concatenate([-cfg[10] * np.ones(N), (-cfg[9] - x0_7[6]) * np.ones(N - 1)])
     up = np.concatenate([cfg[10] * np.ones(N), (cfg[9] - x0_7[6]) * np.ones(N - 1)])
+    if terminal_C is not None and len(terminal_C):
+        C = np.asarray(terminal_C, dtype=np.float64)
+        A = np.vstack([A, C @ G[N][1:, :]])
+        up = np.concatenate([up, 1.0 + C @ xr[N, 1:] - C @ xs[N][1:]])
+        lo = np.concatenate([lo, np.full(C.shape[0], -np.inf)])
     return H, g, A, lo, up
 
 

@@ -1,0 +1,78 @@
+"""Terminal-set pieces that need no GPU: the checker's solve with terminal rows against a dense KKT certificate, and the
+host-side set estimate (stability.py:7-112 of the reference; parity unpinned: the reference holds no fixture for these
+functions and cvxpy / ECOS are absent, the LP optima are HiGHS's)."""
+import numpy as np
+import pytest
+
+
+def _problem(orc, rng, N, Tf):
+    psi = rng.uniform(-0.1, 0.1)
+    s = np.array([15 + rng.uniform(0, 30), rng.uniform(-0.3, 0.3), np.cos(psi), np.sin(psi), 8.0, rng.uniform(-.2, .2),
+                  rng.uniform(-.2, .2), rng.uniform(-.28, .28)])
+    wp, sp, _, _ = orc.skidpad_waypoints(s[0], s[1], np.arctan2(s[3], s[2]), 0, 0.0, s[4], N, Tf / N)
+    return s[[0, 1, 2, 3, 5, 6, 7]], wp, sp
+
+
+@pytest.mark.parametrize("prec", ["f64", "f80"])
+def test_checker_solve_with_terminal_rows_satisfies_kkt(prec):
+    from scipy.optimize import nnls
+    from oracle import oracle as O
+    orc = O.Oracle(prec)
+    N, Tf = 50, 0.5
+    cfg = O.make_cfg("L", N, Tf)
+    rng = np.random.default_rng(1)
+    nactive = 0
+    for trial in range(8):
+        x0, wp, sp = _problem(orc, rng, N, Tf)
+        _, tr0, U0, _, _ = orc.optimize(cfg, x0, wp, sp)
+        e = np.array([tr0[N, 1] - wp[N, 1], np.arcsin(tr0[N, 3]) - wp[N, 3], tr0[N, 4], tr0[N, 5], tr0[N, 6]])
+        d = np.zeros(5); d[1:] = rng.standard_normal(4) * np.array([1.0, 0.3, 0.3, 1.0])
+        C = np.array([d / (0.85 * (d @ e)), rng.standard_normal(5) / (5 * np.abs(e).sum() + 1.0)])   # one cutting, one loose
+        orc.set_terminal_set(C)
+        try:
+            st, tr, U, _, info = orc.optimize(cfg, x0, wp, sp)
+        finally:
+            orc.set_terminal_set(None)
+        if st == 2:
+            continue                                # the cut cannot be reached within the input bounds
+        H, g, A, lo, up = O.condensed_qp(cfg, x0, wp, sp, terminal_C=C)
+        v = A @ U
+        assert (v <= up + 1e-9).all() and (v >= lo - 1e-9).all()
+        at_up = v >= up - 1e-7; at_lo = v <= lo + 1e-7
+        G = np.hstack([A[at_up].T, -A[at_lo].T])
+        rn = nnls(G, -(H @ U + g))[1]
+        assert rn <= 1e-8 * max(1.0, np.abs(g).max()), (trial, rn)
+        assert at_up[2 * N - 1] and np.abs(U - U0).max() > 1e-4      # the cutting row is active and moved the solution
+        nactive += 1
+    assert nactive >= 4
+    # without rows the solver is back to the problem without the set
+    x0, wp, sp = _problem(orc, rng, N, Tf)
+    a = orc.optimize(cfg, x0, wp, sp)[2]
+    orc.set_terminal_set(np.zeros((0, 5)))
+    np.testing.assert_array_equal(a, orc.optimize(cfg, x0, wp, sp)[2])
+
+
+def test_terminal_set_estimate_on_the_host():
+    """estimate_control_amissible_invariant_set with the L controller's (K, A, B): rows = 2 (5 + 1) per power of the
+    closed loop, equal to reconstruct_control_amissible_invariant_set at the stopping index, and the polytope is what the
+    loop's test says: every point of it keeps the state and input constraints for the next steps of x+ = (A - B K) x."""
+    from mpc_amd.controllers import LOcp
+    from mpc_amd import stability as S
+    ctl = LOcp(50, 0.5, _host_only=True)
+    C = ctl.terminal_set_estimate()
+    assert C is ctl.terminal_set_estimate()                  # computed once
+    A, B, K = ctl.A_stability.astype(np.float64), ctl.B_stability.astype(np.float64), ctl.K
+    ubx = np.array([100, 100, 100, 100, ctl.max_steering]); ubu = np.array([ctl.max_steering_rate])
+    assert C.shape[1] == 5 and C.shape[0] % 12 == 0
+    n = C.shape[0] // 12 - 1
+    assert 2 <= n <= 1000
+    np.testing.assert_array_equal(C, S.reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu))
+    phi = A - B @ K
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((400, 5)) * np.array([0.5, 0.1, 1.0, 1.0, 0.05])
+    pts *= (rng.uniform(0.2, 1.0, 400) / (pts @ C.T).max(axis=1))[:, None]      # the set contains the origin: scale rays into it
+    assert (pts @ C.T <= 1 + 1e-12).all()
+    x = pts.T
+    for _ in range(n):
+        assert (np.abs(x) <= ubx[:, None] * (1 + 1e-9)).all() and (np.abs(K @ x) <= ubu[:, None] * (1 + 1e-9)).all()
+        x = phi @ x
