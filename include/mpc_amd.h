@@ -41,7 +41,7 @@ extern "C" {
 #define MPC_KIND_L 0      /* LMPC2.py   LOcp   */
 #define MPC_KIND_OFL 1    /* OFLMPC2.py OFLOcp */
 #define MPC_KIND_LPV 2    /* LPVMPC.py  LPVOcp */
-#define MPC_KIND_NL 3     /* NLMPC.py   NLOcp  (horizons 10, 20, 30, 40, 50, 64) */
+#define MPC_KIND_NL 3     /* NLMPC.py   NLOcp  (any horizon 2..64) */
 
 #define MPC_PLANNER_SKIDPAD 0 /* utils/path_planning.py SkidpadPlanner */
 #define MPC_PLANNER_STEP 1    /* utils/step_planning.py StepPlanner    */

@@ -88,7 +88,7 @@ static const char *check_config(const mpc_config *cfg)
     if (cfg->B < 1 || !(cfg->dt > 0.0)) return "need B >= 1 and dt > 0";
     if (!(cfg->step_ramp_length >= 0.0)) return "step_ramp_length must be >= 0";
     if (cfg->kind == MPC_KIND_NL) {
-        if (!mpc::horizon_templated(cfg->N)) return "the NL controller needs a horizon of 10, 20, 30, 40, 50 or 64";
+        if (!mpc::nl_horizon_capacity(cfg->N)) return "the NL controller needs a horizon of 2..64";
         if (!(cfg->w_nl[7] > 0.0)) return "input weight w_nl[7] must be positive (strict convexity)";
     } else if (!(cfg->w[6] > 0.0)) return "input weight R*r must be positive (strict convexity)";
     if (cfg->solver_layout < MPC_LAYOUT_AUTO || cfg->solver_layout > MPC_LAYOUT_LANE) return "unknown solver_layout";
@@ -119,7 +119,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     fill_devcfg(cfg, h->dev);
     DeviceScope scope(cfg->device);
     hipError_t e = scope.err;
-    const size_t B = (size_t)cfg->B, N = (size_t)cfg->N;
+    // condensed Hessians: N x N per scenario; the NL kernels lay theirs out for the instantiation that runs the horizon
+    const size_t B = (size_t)cfg->B, N = (size_t)(cfg->kind == MPC_KIND_NL ? mpc::nl_horizon_capacity(cfg->N) : cfg->N);
     if (e == hipSuccess && !h->lanes) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
     if (e == hipSuccess && h->lanes) e = hipMalloc(&h->lane_ws, mpc::lanes_workspace_doubles(cfg->N, cfg->B, 0) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));

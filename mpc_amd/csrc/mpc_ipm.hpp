@@ -147,8 +147,12 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
     Newton<N> nt;
     double U, mu, res;
     int iters;
-    const bool valid = lane < N, validd = lane < N - 1;
+    // number of inputs of the problem: N, except for the NL kernels, which run any horizon up to N on the instantiation
+    // for N (the rows beyond nu are unconstrained unit rows of the Newton matrix with a zero right-hand side)
+    const int nu = (TAG == 3) ? prm.nu : N;
+    const bool valid = lane < nu, validd = lane < nu - 1;
     const int lc = valid ? lane : 0;
+    const int lr = (TAG == 3) ? (lane < N ? lane : 0) : lc;      // row of H this lane holds (rows nu..N-1 exist in the NL kernels)
     const double dt = prm.dt, dt2 = dt * dt;
     const double umax = prm.umax, dmax = prm.dmax;
     const double gscale = fmax(1.0, wave_max(fabs(g)));
@@ -173,10 +177,10 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         double u0 = w[lc], a0 = w[WAVE + lc], a1 = w[2 * WAVE + lc], a2 = w[3 * WAVE + lc], a3 = w[4 * WAVE + lc];
         if (prm.warm_mode == 2) {
             // the record of the next stage, straight from memory (no cross-lane shuffle of loaded values)
-            const int ln = min(lc + 1, N - 1);
+            const int ln = min(lc + 1, nu - 1);
             const double un = w[ln], b0 = w[WAVE + ln], b1 = w[2 * WAVE + ln], b2 = w[3 * WAVE + ln], b3 = w[4 * WAVE + ln];
-            if (lane < N - 1) { u0 = un; a0 = b0; a1 = b1; }
-            if (lane < N - 2) { a2 = b2; a3 = b3; }
+            if (lane < nu - 1) { u0 = un; a0 = b0; a1 = b1; }
+            if (lane < nu - 2) { a2 = b2; a3 = b3; }
         }
         const double delta = 3e-3;
         U = valid ? fmin(fmax(u0, -umax), umax) : 0.0;
@@ -189,7 +193,7 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
     }
     if (!valid) { tpu = 1.0; tmu = 1.0; lpu = 0.0; lmu = 0.0; }
     if (!validd) { tpd = 1.0; tmd = 1.0; lpd = 0.0; lmd = 0.0; }
-    const double inv_nc = 1.0 / (2.0 * (2 * N - 1));
+    const double inv_nc = 1.0 / (2.0 * (2 * nu - 1));
     double res_prev = 1e300, U_last = 0.0, mu_last = 0.0, res_last = 0.0;
     bool acc_last = false, rec_ok = true;      // rec_ok: the multipliers belong to the returned inputs (warm-start record)
     int status = 0;
@@ -204,7 +208,7 @@ static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane,
         // takes H U from it, and the Newton matrix is then built in place.
         const gdouble *Hr = (const gdouble *)opaque_uniform(Hm);
 #pragma unroll
-        for (int j = 0; j < N; j++) nt.row[j] = Hr[j * N + lc];
+        for (int j = 0; j < N; j++) nt.row[j] = Hr[j * N + lr];
         __builtin_amdgcn_sched_barrier(0);
         double hu = 0.0;
 #pragma unroll

@@ -84,7 +84,8 @@ inline hipError_t allow_big_lds(const void *kernel, bool (&done)[MPC_MAX_DEVICES
 }
 
 hipError_t launch_mpc(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);
-hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);    // MPC_KIND_NL, horizons of MPC_HORIZONS
+hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);    // MPC_KIND_NL, any horizon 2..64: runs on the instantiation nl_horizon_capacity(N)
+int nl_horizon_capacity(int N);    // smallest horizon of MPC_HORIZONS >= N (0: none); the Hessian scratch of an NL handle is B * capacity^2
 hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st);   // run-time horizon, no cache
 // one lane per scenario, stage-wise interior point (kinds L / OFL / LPV, any horizon); ws holds
 // lanes_workspace_doubles(N, Bcap) doubles laid out for a capacity of Bcap scenarios, and keeps the warm-start record between calls

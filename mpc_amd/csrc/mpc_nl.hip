@@ -116,9 +116,13 @@ __device__ __forceinline__ void nl_linearise(const double *x, double u, double h
 template <int N>
 __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const SolveArgs a)
 {
+    // N is the capacity of this instantiation (registers, LDS and the Hessian scratch are laid out for it); the horizon
+    // of the problem is Ne = cfg.N <= N.  Inputs Ne..N-1 do not exist in the problem: their rows of the condensed
+    // Hessian are wr on the diagonal with a zero gradient, so they stay zero and touch nothing.
     const int lane = threadIdx.x;
+    const int Ne = cfg.N;
     const int s = a.order ? a.order[blockIdx.x] : blockIdx.x;      // scenario this wave advances (grid = B workgroups)
-    const bool valid = lane < N, validd = lane < N - 1;
+    const bool valid = lane < Ne, validd = lane < Ne - 1;
     extern __shared__ double lds[];
     double *s_ref = lds;                              // [4][N+1]: x, y, cos, sin of the car-frame waypoints
     double *s_p = s_ref + 4 * (N + 1);                // [N+1] speeds
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         if (a.mode == MODE_SKIDPAD) { lapv = a.lap[s]; prevp = a.prev_progress[s]; }
     }
     const PlantCoef pc = plant_coef(mp, plant[4]);             // constant over the launch: x[4] has zero derivative
-    const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
-    double U = valid ? a.lin_u[(size_t)s * N + lane] : 0.0;    // SQP iterate, carried from call to call
+    const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= Ne) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
+    double U = valid ? a.lin_u[(size_t)s * Ne + lane] : 0.0;   // SQP iterate, carried from call to call
     double *warm_rec = a.ipm_ws ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && a.mode != MODE_SOLVE && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
@@ -167,11 +171,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         if (a.mode == MODE_SOLVE) {
             const double *x0 = a.x0 + 7 * (size_t)s;
             xh[4] = x0[4]; xh[5] = x0[5]; xh[6] = x0[6];
-            for (int k = lane; k <= N; k += WAVE) {
-                const double *w = a.wp + ((size_t)s * (N + 1) + k) * 4;
+            for (int k = lane; k <= Ne; k += WAVE) {
+                const double *w = a.wp + ((size_t)s * (Ne + 1) + k) * 4;
 #pragma unroll
                 for (int c = 0; c < 4; c++) s_ref[c * (N + 1) + k] = w[c];   // NLMPC.py:208-212
-                s_p[k] = a.p[(size_t)s * (N + 1) + k];
+                s_p[k] = a.p[(size_t)s * (Ne + 1) + k];
             }
         } else {
             const double px = plant[0], py = plant[1];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 p0 = px;
             double ch, sh;
             unit_heading(plant[2], plant[3], ch, sh);
-            for (int k = lane; k <= N; k += WAVE) {
+            for (int k = lane; k <= Ne; k += WAVE) {
                 double o[4];
                 const double q = (k == 0) ? p0 : p0 + (k < WAVE ? cs0 : cs1) * dt;
                 if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 for (int c = 0; c < 4; c++) s_ref[c * (N + 1) + k] = o[c];
                 s_p[k] = tvel;
                 if (a.wp_out) {
-                    double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
+                    double *w = a.wp_out + ((size_t)s * (Ne + 1) + k) * 4;
                     w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
                 }
             }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
 #pragma unroll
             for (int i = 0; i < 7; i++) { x[i] = xh[i]; keep[i] = xh[i]; }
 #pragma unroll 1
-            for (int k = 0; k < N; k++) {
+            for (int k = 0; k < Ne; k++) {
                 NlCoef ck;
                 ck.vx = s_p[k]; ck.a11 = s_coef[k * 4]; ck.a12 = s_coef[k * 4 + 1]; ck.a21 = s_coef[k * 4 + 2];
                 ck.a22 = s_coef[k * 4 + 3]; ck.b1 = b1; ck.b2 = b2;
@@ -240,12 +244,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             }
             if (last) {                       // the pass after the final step only produces the prediction
                 if (valid) {
-                    double *o = a.traj_out + ((size_t)s * (N + 1) + lane) * 7;
+                    double *o = a.traj_out + ((size_t)s * (Ne + 1) + lane) * 7;
 #pragma unroll
                     for (int i = 0; i < 7; i++) o[i] = keep[i];
                 }
                 if (lane == 0) {
-                    double *o = a.traj_out + ((size_t)s * (N + 1) + N) * 7;
+                    double *o = a.traj_out + ((size_t)s * (Ne + 1) + Ne) * 7;
 #pragma unroll
                     for (int i = 0; i < 7; i++) o[i] = x[i];
                 }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             }
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < 7; i++) s_x[N * 7 + i] = x[i];
+                for (int i = 0; i < 7; i++) s_x[Ne * 7 + i] = x[i];
             }
             // 2b. derivative of the RK4 map per stage
             if (valid) nl_linearise(keep, U, dt, cl, &s_stage[lane * NL_STAGE_W]);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 for (int i = 0; i < N; i++) nt.row[i] = 0.0;
                 double v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-                for (int k = 1; k <= N; k++) {
+                for (int k = 1; k <= Ne; k++) {
                     const double *stl = &s_stage[(k - 1) * NL_STAGE_W];
                     double st[NL_STAGE_W];                // the stage record in one batch of LDS reads (otherwise the
 #pragma unroll                                             // scheduler waits for each value where it is used)
@@ -310,17 +314,17 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                     }
                     double wv[7];
 #pragma unroll
-                    for (int c = 0; c < 7; c++) wv[c] = (k < N ? wq[c] : wN[c]) * v[c];
+                    for (int c = 0; c < 7; c++) wv[c] = (k < Ne ? wq[c] : wN[c]) * v[c];
 #pragma unroll
                     for (int c = 0; c < 7; c++) g = fma(wv[c], errk[c], g);
-                    if (valid) {
+                    if (lane < N) {             // the columns of the inputs beyond Ne are zero (v never leaves zero there)
 #pragma unroll
                         for (int c = 0; c < 7; c++) s_wv[c * N + lane] = wv[c];
                     }
                     wave_sync();
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
-                        if ((k < N ? wq[c] : wN[c]) != 0.0) {
+                        if ((k < Ne ? wq[c] : wN[c]) != 0.0) {
                             axpy_from_lds<N>(nt.row, &s_wv[c * N], v[c]);
                         }
                     }
@@ -339,11 +343,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             const int lane_d = opaque_int(lane);      // out of hoisted, spilled registers
 #pragma unroll
             for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
-            if (valid) {                            // one divergent region for all N stores, not one per entry
+            if (lane < N) {                         // one divergent region for all N stores, not one per entry
                 store_column<N>(Hw + lane, nt.row);
             }
             nt.template factor<false>(lane, (ldouble *)s_wv);
-            double Un = valid ? nt.solve(-gq, lane) : 0.0;
+            double Un = nt.solve(gq == 0.0 ? 0.0 : -gq, lane);   // every lane takes part: the rows beyond Ne are unit rows with a zero right-hand side
+            if (!valid) Un = 0.0;
             const double vd = dt * incl_prefix(Un, lane);
             bool ok = fabs(Un) <= umax;
             if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 // start from the previous QP's interior-point solve: the previous SQP iteration's, or the previous
                 // closed-loop step's moved one stage ahead
                 const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
-                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm};
+                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm, Ne};
                 const IpmResult r = interior_point<N, 3>(prm, lane, Hw, gq, up_d, lo_d, (ldouble *)s_wv);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         status_max = max(status_max, status);
 
         // ------------------------------------------------------------ 3. outputs and plant
-        if (valid && a.U_out) a.U_out[(size_t)s * N + lane] = U;
+        if (valid && a.U_out) a.U_out[(size_t)s * Ne + lane] = U;
         u0 = bcast(U, 0);
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         wave_sync();
     }
 
-    if (valid) a.lin_u[(size_t)s * N + lane] = U;
+    if (valid) a.lin_u[(size_t)s * Ne + lane] = U;
     if (warm_rec && lane == 0) warm_rec[5 * WAVE] = (warm_ok && a.mode != MODE_SOLVE) ? 1.0 : 0.0;
     if (a.mode != MODE_SOLVE) {
         if (lane < 8) {
@@ -426,9 +431,18 @@ static hipError_t launch_nl_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t
     return hipGetLastError();
 }
 
+// smallest instantiated horizon that holds N stages (0: none)
+int nl_horizon_capacity(int N)
+{
+#define MPC_CASE(n) if (N >= 2 && N <= n) return n;
+    MPC_HORIZONS(MPC_CASE)
+#undef MPC_CASE
+    return 0;
+}
+
 hipError_t launch_mpc_nl(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 {
-    switch (cfg.N) {
+    switch (nl_horizon_capacity(cfg.N)) {
 #define MPC_CASE(n) case n: return launch_nl_n<n>(cfg, a, st);
         MPC_HORIZONS(MPC_CASE)
 #undef MPC_CASE

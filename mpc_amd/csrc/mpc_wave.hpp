@@ -250,7 +250,7 @@ __device__ __forceinline__ void ekf_measurement_update_wave(int lane, double *xe
 // last solve, [5][64], then a validity flag; the any-horizon kernel uses the same layout with rows of 128);
 // warm_mode 0 = cold start, 1 = start from the record, 2 = start from the record moved one stage ahead (the next
 // closed-loop step).  The record is rewritten at exit whenever warm != nullptr.
-struct IpmParams { double dt, umax, dmax, tol_mu, tol_res; int max_iter; double *warm; int warm_mode; };
+struct IpmParams { double dt, umax, dmax, tol_mu, tol_res; int max_iter; double *warm; int warm_mode; int nu; };   // nu: see interior_point()
 struct IpmResult { double U, mu, res; int iters, status; bool warm_valid; };   // warm_valid: the record may start the next solve
 
 
