@@ -445,8 +445,8 @@ def main() -> None:
             ach = mbytes * B * steps_per_launch / launch_s / 1e9
             out["roofline"] = dict({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS},
                                    **common, algorithmic_bytes_per_scenario_step=mbytes, fp64=fp64,
-                                   note="workspace streaming of the stage-wise interior point (method bytes); a wave also runs at the "
-                                        "issue rate of its own instruction stream, see DESIGN.md")
+                                   note="workspace streaming of the stage-wise interior point (method bytes); at this batch size a wave "
+                                        "also runs alone on its compute unit, at the issue rate of its own instruction stream")
         else:
             out["roofline"] = dict({"bound": "mfma"}, **fp64, **common,
                                    note="FP64 vector/matrix peak; the kernels are latency- and issue-bound, not FP64-throughput-bound",
