@@ -17,6 +17,7 @@ struct mpc_handle {
     double *stat = nullptr;      // B * 4 solver records
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     int *work = nullptr, *order = nullptr;     // load balance of chained launches: last launch's iterations, scenario order
+    int *queue = nullptr;                      // work queue counters of the fixed-model kernel (two ints, zero between launches)
     int order_B = 0;                           // batch size `order` is a permutation for (0: none yet)
     double *mp_scen = nullptr;   // optional B * 6
     double *cost_scen = nullptr; // optional B * 43 per-scenario cost weights
@@ -128,6 +129,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->work, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->order, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->queue, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->queue, 0, 2 * sizeof(int));
     if (e == hipSuccess && !cfg->ipm_cold_start) {
         e = hipMalloc(&h->ipm_ws, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
         if (e == hipSuccess) e = hipMemset(h->ipm_ws, 0, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
@@ -151,7 +154,7 @@ void mpc_destroy(mpc_handle *h)
     (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
-    (void)hipFree(h->work); (void)hipFree(h->order);
+    (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
     delete h;
 }
 
@@ -263,7 +266,7 @@ static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStr
 // out as a chain of launches so that the order can follow the work.  Per scenario nothing changes: its state lives in
 // the caller's arrays between launches exactly as between two calls, and which wave advances it has no influence on
 // its arithmetic.
-static const int BAL_CHUNK = 1024, BAL_MIN_B = 1024, BAL_MIN_STEPS = 16;
+static const int BAL_CHUNK = 1024, BAL_MIN_B = 1024, BAL_MIN_STEPS = 4;
 
 static hipError_t launch_chain(mpc_handle *h, const mpc::SolveArgs &a, hipStream_t st)
 {
@@ -285,6 +288,7 @@ static hipError_t launch_chain(mpc_handle *h, const mpc::SolveArgs &a, hipStream
         c.order = h->order_B == a.B ? h->order : nullptr;
         const bool rank = c.nsteps >= BAL_MIN_STEPS;            // a short launch says little and the sort is not free
         c.work_out = rank ? h->work : nullptr;
+        c.queue = c.nsteps >= 2 ? h->queue : nullptr;           // one step per launch: every wave has the same short job
         hipError_t e = launch_for_kind(h, c, st);
         if (e != hipSuccess) return e;
         if (rank) {
@@ -398,6 +402,7 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream)
     // layout); clearing the whole block covers both
     if (h->ipm_ws) HIP_TRY(h, hipMemsetAsync(h->ipm_ws, 0, (size_t)h->cfg.B * mpc::IPM_WARM_DOUBLES * sizeof(double), (hipStream_t)stream));
     h->order_B = 0;
+    if (h->queue) HIP_TRY(h, hipMemsetAsync(h->queue, 0, 2 * sizeof(int), (hipStream_t)stream));
     return MPC_OK;
 }
 

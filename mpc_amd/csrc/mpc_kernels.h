@@ -57,6 +57,10 @@ struct SolveArgs {
     const int *order;
     int *work_out;
     int accumulate;
+    // Optional work queue of the fixed-model kernel: two ints, {next position in `order`, waves that have left}, both zero
+    // between launches.  With it the launch holds only as many workgroups as the GPU keeps resident and every wave takes
+    // the next scenario when it has finished one, instead of a workgroup holding its slot until its slowest wave is done.
+    int *queue;
     // Fixed-model cache (every scenario at speed sh_vx with the handle's model parameters); NULL = off.
     const double *sh_H;      // [N][N] condensed Hessian
     const double *sh_Kref;   // [3][N][N]: inv(H) * d g / d ref_c(stage k+1), stored [c][k][i]

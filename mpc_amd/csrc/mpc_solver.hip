@@ -129,8 +129,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps scenario addressing scalar
     const int lane = threadIdx.x & 63;
-    const int widx = blockIdx.x * WPB + wave;
-    const int s = (a.order && widx < a.B) ? a.order[widx] : widx;       // scenario this wave advances
+    int widx = blockIdx.x * WPB + wave;
+    int s = (a.order && widx < a.B) ? a.order[widx] : widx;             // scenario this wave advances
     const bool valid = lane < N;        // lane owns a decision variable
     const bool validd = lane < N - 1;   // lane owns the bound on delta_{lane+1}
 
@@ -159,7 +159,24 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         for (int i = threadIdx.x; i < 5 * N; i += WPB * WAVE) s_Kx[i] = a.sh_Kx[i];
         __syncthreads();                 // the only workgroup-wide barrier: from here on the waves are independent
     }
-    if (widx >= a.B) return;
+    // Work queue (fixed-model kernel, fused launches): the wave takes scenarios from `order` until none is left.  The
+    // last wave to leave puts the two counters back to zero for the next launch.
+    const bool pull = !GENERAL && a.queue != nullptr;
+#pragma unroll 1
+    for (;;) {
+    if (pull) {
+        int w = 0;
+        if (lane == 0) w = atomicAdd(a.queue, 1);
+        widx = __builtin_amdgcn_readfirstlane(w);
+        if (widx >= a.B) {
+            if (lane == 0 && atomicAdd(a.queue + 1, 1) == (int)(gridDim.x * WPB) - 1) {
+                __atomic_store_n(a.queue, 0, __ATOMIC_RELAXED); __atomic_store_n(a.queue + 1, 0, __ATOMIC_RELAXED);
+            }
+            return;
+        }
+        s = a.order ? a.order[widx] : widx;
+    } else if (widx >= a.B)
+        return;
 
     ModelParams mp;
     if (a.mp_scen) {
@@ -443,6 +460,9 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
     }
+    if (!pull) return;
+    wave_sync();            // the wave's LDS areas are reused by its next scenario
+    }   // work queue
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,7 +541,25 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_area);
         static bool lds_ok[MPC_MAX_DEVICES] = {};
         if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false>), lds_ok)) return e;
-        hipLaunchKernelGGL((k_mpc<N, false>), dim3((a.B + FIXED_WPB - 1) / FIXED_WPB), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
+        int blocks = (a.B + FIXED_WPB - 1) / FIXED_WPB;
+        if (a.queue) {
+            // as many workgroups as stay resident (fewer when the batch is smaller): their waves share the whole batch
+            // (looked up once per device and LDS size: the property query is slow)
+            static int cached_resident[MPC_MAX_DEVICES] = {};
+            static size_t cached_lds[MPC_MAX_DEVICES] = {};
+            int dev = 0;
+            if (hipError_t e = hipGetDevice(&dev)) return e;
+            const int slot = dev >= 0 && dev < MPC_MAX_DEVICES ? dev : 0;
+            if (!cached_resident[slot] || cached_lds[slot] != lds) {
+                int per_cu = 0, cus = 0;
+                if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return e;
+                if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_mpc<N, false>), FIXED_WPB * WAVE, lds)) return e;
+                cached_resident[slot] = per_cu * cus; cached_lds[slot] = lds;
+            }
+            const int resident = cached_resident[slot];
+            if (resident >= 1 && resident < blocks) blocks = resident;
+        }
+        hipLaunchKernelGGL((k_mpc<N, false>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
         const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36);

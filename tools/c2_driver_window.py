@@ -32,7 +32,8 @@ print(f"all 4096 fused: {ms:.2f} ms, iterations per scenario over the 20 steps: 
 ms, _ = window(np.arange(B), per_step=True)
 print(f"all 4096 per-step launches: {ms:.2f} ms")
 srt = np.argsort(-it)
-for name, idx in (("heaviest 1", srt[:1]), ("heaviest 64", srt[:64]), ("heaviest 1024", srt[:1024]), ("heaviest 2048", srt[:2048]),
+for name, idx in (("lightest 1024", srt[-1024:]), ("lightest 64", srt[-64:]), ("heaviest 512 + lightest 512", np.concatenate([srt[:512], srt[-512:]])), ("heaviest 1024 + lightest 1024", np.concatenate([srt[:1024], srt[-1024:]])), ("heaviest 2048 + lightest 1024", np.concatenate([srt[:2048], srt[-1024:]])),
+                  ("heaviest 2048 + next 1024", srt[:3072]), ("ranks 1024..3072", srt[1024:3072]), ("heaviest 1", srt[:1]), ("heaviest 64", srt[:64]), ("heaviest 1024", srt[:1024]), ("heaviest 2048", srt[:2048]),
                   ("lightest 2048", srt[-2048:])):
     ms, i2 = window(np.sort(idx))
     print(f"{name:16s}: {ms:.2f} ms  (iterations mean {i2.mean():.1f} max {i2.max()})")
