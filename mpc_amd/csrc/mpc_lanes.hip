@@ -173,18 +173,14 @@ __device__ __forceinline__ void mulAt(const StageM &s, const ScenM &m, const dou
     y[5] = m.f35 * v[3] + m.f45 * v[4] + v[5];
 }
 
-// Largest ratio -d / v over the entries that move towards zero, kept as a fraction (num / den, den > 0) so that no
-// reciprocal is needed per entry: the step to the boundary is den / num when num > den.
+// Largest ratio -d / v over the slacks and multipliers v > 0 with directions d: the step to the boundary is its
+// reciprocal when it exceeds one.  The reciprocals of the slacks are at hand (the directions need them); those of the
+// multipliers come from the hardware's approximate reciprocal alone (about 1e-8 relative), which is enough here: the step
+// is shortened by at least 1e-6 afterwards, so an iterate never reaches the boundary because of it.
 struct Ratio {
-    double num = 0.0, den = 1.0;
-    __device__ __forceinline__ void add(double v, double d)
-    {
-        const double n = -d;                      // candidate n / v against num / den
-        const bool take = n * den > num * v;
-        num = take ? n : num; den = take ? v : den;
-    }
-    __device__ __forceinline__ void merge(const Ratio &o) { add(o.den, -o.num); }
-    __device__ __forceinline__ double step() const { return num > den ? den / num : 1.0; }
+    double rmax = 0.0;
+    __device__ __forceinline__ void add(double d, double inv_v) { rmax = fmax(rmax, -d * inv_v); }
+    __device__ __forceinline__ double step() const { return rmax > 1.0 ? fast_rcp(rmax) : 1.0; }
 };
 
 struct LaneProb {
@@ -507,11 +503,9 @@ __device__ __forceinline__ Con4 bound_dirs(const Con4 &t, const Con4 &aff, doubl
     else if (mode == 2) { rcp -= sigmu; rcm -= sigmu; }
     Con4 d;
     d.tp = -rpp - dv; d.tm = -rpm + dv;
-    d.lp = -(rcp + t.lp * d.tp) * fast_rcp(t.tp); d.lm = -(rcm + t.lm * d.tm) * fast_rcp(t.tm);
-    Ratio a, b;                                   // two short chains instead of one of four dependent updates
-    a.add(t.tp, d.tp); b.add(t.tm, d.tm); a.add(t.lp, d.lp); b.add(t.lm, d.lm);
-    a.merge(b);
-    r.merge(a);
+    const double itp = fast_rcp(t.tp), itm = fast_rcp(t.tm);
+    d.lp = -(rcp + t.lp * d.tp) * itp; d.lm = -(rcm + t.lm * d.tm) * itm;
+    r.add(d.tp, itp); r.add(d.tm, itm); r.add(d.lp, __builtin_amdgcn_rcp(t.lp)); r.add(d.lm, __builtin_amdgcn_rcp(t.lm));
     ps.s0 += t.tp * t.lp + t.tm * t.lm;
     ps.s1 += t.tp * d.lp + t.lp * d.tp + t.tm * d.lm + t.lm * d.tm;
     ps.s2 += d.tp * d.lp + d.tm * d.lm;
@@ -563,8 +557,9 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
             double rc = t * l;
             if (mode == 1) rc += (double)c.term(TF_DT, i) * (double)c.term(TF_DL, i) - sigmu; else if (mode == 2) rc -= sigmu;
             const double d_t = -(term_dot(cr, e) + t - 1.0) - term_dot(cr, dxe);
-            const double d_l = -(rc + l * d_t) * fast_rcp(t);
-            r.add(t, d_t); r.add(l, d_l);
+            const double it = fast_rcp(t);
+            const double d_l = -(rc + l * d_t) * it;
+            r.add(d_t, it); r.add(d_l, __builtin_amdgcn_rcp(l));
             ps.s0 += t * l; ps.s1 += t * d_l + l * d_t; ps.s2 += d_t * d_l;
             c.term(TF_DT, i) = d_t; c.term(TF_DL, i) = d_l;
         }
