@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmpc_amd.so")
 SOURCES = ["mpc_solver.hip", "mpc_generic.hip", "mpc_lanes.hip", "mpc_nl.hip", "mpc_aux.hip", "mpc_abi.hip"]
+# second builds of a source with other macros: (source, object name, flags).  mpc_lanes.hip without the longitudinal
+# position in its recursions (see LANE_X0 there).
+VARIANTS = [("mpc_lanes.hip", "mpc_lanes_nopx.o", ["-DLANE_X0=1"])]
 HEADERS = ["mpc_device.hpp", "mpc_wave.hpp", "mpc_ipm.hpp", "mpc_kernels.h", os.path.join("..", "..", "include", "mpc_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Machine LICM hoists the literal constants of the inlined math routines out of the in-kernel step loop and then
@@ -41,16 +44,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src, objname, extra = job
+        obj = os.path.join(objdir, objname)
+        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    jobs = [(s, s.replace(".hip", ".o"), []) for s in SOURCES] + VARIANTS
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        objs = list(ex.map(compile_one, jobs))
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 

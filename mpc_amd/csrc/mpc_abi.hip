@@ -3,6 +3,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "mpc_kernels.h"
 
@@ -23,6 +24,7 @@ struct mpc_handle {
     double *cost_scen = nullptr; // optional B * 43 per-scenario cost weights
     double *term_C = nullptr;    // optional terminal set rows [term_m][5] (lane layout)
     int term_m = 0;
+    bool px_free = false;        // nothing weighs the longitudinal position (controller weights, or every row of cost_scen)
     double *stats16 = nullptr;   // device result of the statistics reduction
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double sh_vx = 0.0;
@@ -108,6 +110,15 @@ static void fill_devcfg(const mpc_config *cfg, mpc::DevCfg &d)
     d.eps_nl = cfg->eps_nl; d.sqp_tol = cfg->sqp_tol > 0 ? cfg->sqp_tol : 1e-9; d.sqp_max_iter = cfg->sqp_max_iter > 0 ? cfg->sqp_max_iter : 30;
 }
 
+// true when a cost definition (diag W [7], W_e 6x6 row-major) puts nothing on px: stage weight zero, terminal row and
+// column zero
+static bool weights_px_free(const double *w, const double *We)
+{
+    bool ok = w[0] == 0.0;
+    for (int j = 0; j < 6 && ok; j++) ok = We[j] == 0.0 && We[6 * j] == 0.0;
+    return ok;
+}
+
 int mpc_create(const mpc_config *cfg, mpc_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, MPC_EINVAL, "mpc_create: null argument");
@@ -116,6 +127,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     mpc_handle *h = new (std::nothrow) mpc_handle();
     if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
     h->cfg = *cfg;
+    h->px_free = weights_px_free(cfg->w, cfg->We);
     h->lanes = cfg->solver_layout == MPC_LAYOUT_LANE || (cfg->solver_layout == MPC_LAYOUT_AUTO && cfg->kind == MPC_KIND_LPV);
     fill_devcfg(cfg, h->dev);
     DeviceScope scope(cfg->device);
@@ -174,10 +186,21 @@ int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario)
     if (!h) return MPC_EINVAL;
     ON_HANDLE_DEVICE(h);
     if (h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_set_cost_weights: the NL controller's weights are fixed by its definition");
-    if (!cost_per_scenario) { (void)hipFree(h->cost_scen); h->cost_scen = nullptr; return MPC_OK; }
+    if (!cost_per_scenario) {
+        (void)hipFree(h->cost_scen); h->cost_scen = nullptr;
+        h->px_free = weights_px_free(h->cfg.w, h->cfg.We);
+        return MPC_OK;
+    }
     const size_t bytes = (size_t)h->cfg.B * 43 * sizeof(double);
     if (!h->cost_scen) HIP_TRY(h, hipMalloc(&h->cost_scen, bytes));
     HIP_TRY(h, hipMemcpy(h->cost_scen, cost_per_scenario, bytes, hipMemcpyDeviceToDevice));
+    if (h->lanes) {      // which build of the lane solver the table allows (a set-up call: one copy to the host)
+        std::vector<double> host((size_t)h->cfg.B * 43);
+        HIP_TRY(h, hipMemcpy(host.data(), h->cost_scen, bytes, hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (int b = 0; b < h->cfg.B && ok; b++) ok = weights_px_free(&host[(size_t)b * 43], &host[(size_t)b * 43 + 7]);
+        h->px_free = ok;
+    }
     return MPC_OK;
 }
 
@@ -319,7 +342,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     mpc::SolveArgs a = {};
     a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8; a.x0 = x0; a.wp = wp; a.p = p; a.d_hat = d_hat; a.lin_x = lin_x; a.lin_u = lin_u;
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.U_out = U_out; a.traj_out = traj_out;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;
@@ -361,7 +384,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.state = state; a.lap = lap; a.prev_progress = prev_progress; a.target_vel = target_vel; a.step_ramp = h->cfg.step_ramp_length;
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;
@@ -386,7 +409,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     for (int i = 0; i < 10; i++) a.ekf_q[i] = q_diag_host[i];
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
-    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C;
+    a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B;

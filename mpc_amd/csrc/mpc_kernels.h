@@ -71,6 +71,7 @@ struct SolveArgs {
     // Terminal set C (x_N[1:] - x_ref) <= 1 (lane-per-scenario layout only): rows [term_m][5] in device memory, 0 = none.
     int term_m;
     const double *term_C;
+    int px_free;             // no cost on the longitudinal position anywhere (lane layout: the solver build without px)
 };
 
 // Raises a kernel's dynamic-LDS limit to the CU's 160 KB once per device and kernel (`done` is that kernel's flag table).

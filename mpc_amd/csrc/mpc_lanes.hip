@@ -25,7 +25,23 @@
 
 #pragma clang fp contract(fast)
 
+// This file is compiled twice.  LANE_X0 = 1 builds the solver for problems that put no weight on the longitudinal
+// position px (stage weight and terminal row/column zero: the controllers' parameter files): px drives nothing, so its
+// adjoint and its row and column of the Riccati matrix are exactly zero and everything that would compute or move those
+// zeros is left out.  LANE_X0 = 0 is the general solver (per-scenario cost tables, other weights).  Results are
+// identical: the skipped operations only ever add exact zeros.
+#ifndef LANE_X0
+#define LANE_X0 0
+#endif
+#if LANE_X0
+#define LANE_FN(name) name##_nopx
+#else
+#define LANE_FN(name) name
+#endif
+
 namespace mpc {
+namespace LANE_FN(lanes) {
+constexpr int X0 = LANE_X0;          // first state that takes part in the adjoint and matrix recursions
 
 // workspace fields, each [N + 1][stride] doubles
 enum {
@@ -125,31 +141,36 @@ __device__ __forceinline__ void riccati_matrix_step(Sym6 &P, const StageM &s, co
 {
     Sym6 Q;
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = X0; j < 6; j++) {
         double col[6], o[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = X0; i < 6; i++) {
             double t;
             if (j == 0) t = P(i, 0);
             else if (j == 1) t = P(i, 1);
-            else if (j == 2) t = s.e02 * P(i, 0) + s.e12 * P(i, 1) + P(i, 2);
-            else if (j == 3) t = s.e03 * P(i, 0) + s.e13 * P(i, 1) + s.f33 * P(i, 3) + s.f43 * P(i, 4);
+            else if (j == 2) { t = s.e12 * P(i, 1) + P(i, 2); if (X0 == 0) t += s.e02 * P(i, 0); }
+            else if (j == 3) { t = s.e13 * P(i, 1) + s.f33 * P(i, 3) + s.f43 * P(i, 4); if (X0 == 0) t += s.e03 * P(i, 0); }
             else if (j == 4) t = m.dt * P(i, 2) + s.f34 * P(i, 3) + s.f44 * P(i, 4);
             else t = m.f35 * P(i, 3) + m.f45 * P(i, 4) + P(i, 5);
             col[i] = t;
         }
-        // rows 0..j of A' col
-        o[0] = col[0];
+        // rows X0..j of A' col
+        if (X0 == 0) o[0] = col[0];
         o[1] = col[1];
-        o[2] = s.e02 * col[0] + s.e12 * col[1] + col[2];
-        o[3] = s.e03 * col[0] + s.e13 * col[1] + s.f33 * col[3] + s.f43 * col[4];
+        o[2] = s.e12 * col[1] + col[2];
+        o[3] = s.e13 * col[1] + s.f33 * col[3] + s.f43 * col[4];
+        if (X0 == 0) { o[2] += s.e02 * col[0]; o[3] += s.e03 * col[0]; }
         o[4] = m.dt * col[2] + s.f34 * col[3] + s.f44 * col[4];
         o[5] = m.f35 * col[3] + m.f45 * col[4] + col[5];
 #pragma unroll
-        for (int i = 0; i <= j; i++)
+        for (int i = X0; i <= j; i++)
             Q(i, j) = o[i] - atpb[i] * atpb[j] * ire + ((i == j) ? wq[i] + ((i == 5) ? dx5 : 0.0) : 0.0);
     }
-    P = Q;
+#pragma unroll
+    for (int i = X0; i < 6; i++) {
+#pragma unroll
+        for (int j = i; j < 6; j++) P(i, j) = Q(i, j);
+    }
 }
 
 // y = A x (the linear part of the stage map; b u and c are added by the caller)
@@ -162,13 +183,24 @@ __device__ __forceinline__ void mulA(const StageM &s, const ScenM &m, const doub
     y[4] = s.f43 * x[3] + s.f44 * x[4] + m.f45 * x[5];
     y[5] = x[5];
 }
-// y = A' v
+// y = A x for a direction of the states: component 0 is left out when px takes no part (nothing reads it)
+__device__ __forceinline__ void mulA_dir(const StageM &s, const ScenM &m, const double (&x)[6], double (&y)[6])
+{
+    if (X0 == 0) y[0] = x[0] + s.e02 * x[2] + s.e03 * x[3];
+    y[1] = x[1] + s.e12 * x[2] + s.e13 * x[3];
+    y[2] = x[2] + m.dt * x[4];
+    y[3] = s.f33 * x[3] + s.f34 * x[4] + m.f35 * x[5];
+    y[4] = s.f43 * x[3] + s.f44 * x[4] + m.f45 * x[5];
+    y[5] = x[5];
+}
+// y = A' v (components X0..5; v[0] is zero when px takes no part)
 __device__ __forceinline__ void mulAt(const StageM &s, const ScenM &m, const double (&v)[6], double (&y)[6])
 {
-    y[0] = v[0];
+    if (X0 == 0) y[0] = v[0];
     y[1] = v[1];
-    y[2] = s.e02 * v[0] + s.e12 * v[1] + v[2];
-    y[3] = s.e03 * v[0] + s.e13 * v[1] + s.f33 * v[3] + s.f43 * v[4];
+    y[2] = s.e12 * v[1] + v[2];
+    y[3] = s.e13 * v[1] + s.f33 * v[3] + s.f43 * v[4];
+    if (X0 == 0) { y[2] += s.e02 * v[0]; y[3] += s.e03 * v[0]; }
     y[4] = m.dt * v[2] + s.f34 * v[3] + s.f44 * v[4];
     y[5] = m.f35 * v[3] + m.f45 * v[4] + v[5];
 }
@@ -271,7 +303,7 @@ template <int LPW> __device__ __forceinline__ void store4(const LaneCtxT<LPW> &c
 template <int LPW> __device__ __forceinline__ void load6(const LaneCtxT<LPW> &c, int field, int k, double (&v)[6])
 {
 #pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = c.at(field + i, k);
+    for (int i = X0; i < 6; i++) v[i] = c.at(field + i, k);      // component 0 is not needed when px takes no part
 }
 
 // Roll the states out for the inputs in the workspace: x_0 = xh, x_{k+1} = A_k x_k + b u_k + c_k, stored.  With
@@ -300,12 +332,15 @@ __device__ __forceinline__ void terminal_grad(const LaneCtxT<LPW> &c, const Lane
 {
     double e[6];
     load6(c, LF_X, p.N, e);
-    if (p.xr_term_zero == 0.0) { e[0] -= c.at(LF_REF, p.N); e[1] -= c.at(LF_REF + 1, p.N); e[2] -= c.at(LF_REF + 2, p.N); }
+    if (p.xr_term_zero == 0.0) {
+        if (X0 == 0) e[0] -= c.at(LF_REF, p.N);
+        e[1] -= c.at(LF_REF + 1, p.N); e[2] -= c.at(LF_REF + 2, p.N);
+    }
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = X0; i < 6; i++) {
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) t = fma(p.QN[i * 6 + j], e[j], t);
+        for (int j = X0; j < 6; j++) t = fma(p.QN[i * 6 + j], e[j], t);
         g[i] = t;
     }
 }
@@ -313,7 +348,8 @@ __device__ __forceinline__ void terminal_grad(const LaneCtxT<LPW> &c, const Lane
 // state-cost gradient wq .* (x_k - r_k) from loaded values
 __device__ __forceinline__ void stage_grad(const LaneProb &p, const double (&x)[6], const double (&r)[3], double (&g)[6])
 {
-    g[0] = p.wq[0] * (x[0] - r[0]); g[1] = p.wq[1] * (x[1] - r[1]); g[2] = p.wq[2] * (x[2] - r[2]);
+    if (X0 == 0) g[0] = p.wq[0] * (x[0] - r[0]);
+    g[1] = p.wq[1] * (x[1] - r[1]); g[2] = p.wq[2] * (x[2] - r[2]);
     g[3] = p.wq[3] * x[3]; g[4] = p.wq[4] * x[4]; g[5] = p.wq[5] * x[5];
 }
 
@@ -327,7 +363,8 @@ __device__ __forceinline__ double lane_grad_scale(const LaneCtxT<LPW> &c, const 
     lane_sweep<LN_RING, false, In>(p.N,
         [&](int k) {
             In v; v.s = load_stage(c, k); load6(c, LF_X, k, v.x);
-            v.r[0] = c.at(LF_REF, k); v.r[1] = c.at(LF_REF + 1, k); v.r[2] = c.at(LF_REF + 2, k);
+            if (X0 == 0) v.r[0] = c.at(LF_REF, k);
+            v.r[1] = c.at(LF_REF + 1, k); v.r[2] = c.at(LF_REF + 2, k);
             return v;
         },
         [&](const In &v, int k) {
@@ -336,7 +373,7 @@ __device__ __forceinline__ double lane_grad_scale(const LaneCtxT<LPW> &c, const 
             mulAt(v.s, m, pi, y);
             stage_grad(p, v.x, v.r, g);
 #pragma unroll
-            for (int i = 0; i < 6; i++) pi[i] = g[i] + y[i];
+            for (int i = X0; i < 6; i++) pi[i] = g[i] + y[i];
         });
     return g0;
 }
@@ -356,7 +393,8 @@ __device__ __forceinline__ BackIn load_back(const LaneCtxT<LPW> &c, int k)
     b.u = c.at(LF_U, k);
     if (mode != 3) { b.cu = load4(c, LF_TPU, k); b.cx = load4(c, LF_TPX, k); }
     load6(c, LF_X, k, b.x);
-    b.r[0] = c.at(LF_REF, k); b.r[1] = c.at(LF_REF + 1, k); b.r[2] = c.at(LF_REF + 2, k);
+    if (X0 == 0) b.r[0] = c.at(LF_REF, k);
+    b.r[1] = c.at(LF_REF + 1, k); b.r[2] = c.at(LF_REF + 2, k);
     if (mode == 1) { b.du = load4(c, LF_DTPU, k); b.dx = load4(c, LF_DTPX, k); }
     if (!factor) { load6(c, LF_ATPB, k, b.atpb); b.ire = c.at(LF_IRE, k); }
     return b;
@@ -378,7 +416,7 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
     double pv[6], pi[6], resd = 0.0;
     terminal_grad(c, p, pi);
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = X0; i < 6; i++) {
         pv[i] = pi[i];
 #pragma unroll
         for (int j = i; j < 6; j++) P(i, j) = p.QN[i * 6 + j];
@@ -425,15 +463,15 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
         if (factor) {
             double pb[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) pb[i] = m.dt * P(i, 5);
+            for (int i = X0; i < 6; i++) pb[i] = m.dt * P(i, 5);
             ire = fast_rcp(p.wr + Du + m.dt * pb[5]);
             mulAt(b.s, m, pb, atpb);
 #pragma unroll
-            for (int i = 0; i < 6; i++) c.at(LF_ATPB + i, k) = atpb[i];
+            for (int i = X0; i < 6; i++) c.at(LF_ATPB + i, k) = atpb[i];
             c.at(LF_IRE, k) = ire;
         } else {
 #pragma unroll
-            for (int i = 0; i < 6; i++) atpb[i] = b.atpb[i];
+            for (int i = X0; i < 6; i++) atpb[i] = b.atpb[i];
             ire = b.ire;
         }
         const double kg = -(gu + wu + m.dt * pv[5]) * ire;
@@ -458,11 +496,11 @@ __device__ __forceinline__ double lane_backward(const LaneCtxT<LPW> &c, const La
             double y[6];
             mulAt(b.s, m, pv, y);
 #pragma unroll
-            for (int i = 0; i < 6; i++) pv[i] = gx[i] + y[i] + atpb[i] * kg;
+            for (int i = X0; i < 6; i++) pv[i] = gx[i] + y[i] + atpb[i] * kg;
             pv[5] += wx;
             mulAt(b.s, m, pi, y);
 #pragma unroll
-            for (int i = 0; i < 6; i++) pi[i] = gx[i] + y[i];
+            for (int i = X0; i < 6; i++) pi[i] = gx[i] + y[i];
             if (factor) riccati_matrix_step(P, b.s, m, atpb, ire, p.wq, Dx);
         }
     });
@@ -525,13 +563,13 @@ __device__ __forceinline__ double lane_forward(const LaneCtxT<LPW> &c, const Lan
         const int q = k + 1;
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) acc = fma(f.atpb[i], dx[i], acc);
+        for (int i = X0; i < 6; i++) acc = fma(f.atpb[i], dx[i], acc);
         const double du = f.kg - f.ire * acc;
         double y[6];
-        mulA(f.s, m, dx, y);
+        mulA_dir(f.s, m, dx, y);
         y[5] += m.dt * du;
 #pragma unroll
-        for (int i = 0; i < 6; i++) dx[i] = y[i];
+        for (int i = X0; i < 6; i++) dx[i] = y[i];
         if (mode == 3)
             c.at(LF_U, k) = du;
         else {
@@ -1045,6 +1083,30 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     }
 }
 
+template <int LPW, int WPB>
+static hipError_t launch_lanes_t(const DevCfg &cfg, const SolveArgs &a, double *ws, hipStream_t st)
+{
+    const int nblk = (a.B + LPW - 1) / LPW;
+    hipLaunchKernelGGL((k_mpc_lanes<LPW, WPB>), dim3((nblk + WPB - 1) / WPB), dim3(WPB * WAVE), 0, st, cfg, a, ws);
+    return hipGetLastError();
+}
+
+// this build of the solver (with or without px) for `lpw` lanes per wave
+hipError_t launch_variant(const DevCfg &cfg, const SolveArgs &a, double *ws, int lpw, hipStream_t st)
+{
+    switch (lpw) {
+    case 64: return launch_lanes_t<64, 1>(cfg, a, ws, st);
+    case 32: return launch_lanes_t<32, 1>(cfg, a, ws, st);
+    case 16: return launch_lanes_t<16, 1>(cfg, a, ws, st);
+    default: return launch_lanes_t<8, 1>(cfg, a, ws, st);
+    }
+}
+
+}  // namespace lanes / lanes_nopx
+
+#if !LANE_X0
+namespace lanes_nopx { hipError_t launch_variant(const DevCfg &cfg, const SolveArgs &a, double *ws, int lpw, hipStream_t st); }
+
 // Lanes per wave that carry a scenario, by batch size.  A wave runs alone on its compute unit at the rate its own
 // instruction stream issues, whatever the number of active lanes, so full waves are the cheapest as soon as there are
 // scenarios for them; below that, narrower waves lose fewer iterations to the slowest lane of the wave.  (Measured on the
@@ -1061,15 +1123,7 @@ static int lanes_per_wave(int B)
 size_t lanes_workspace_doubles(int N, int B, int term_m)
 {
     const size_t lpw = (size_t)lanes_per_wave(B);
-    return ((size_t)B + lpw - 1) / lpw * lpw * ((size_t)LN_FIELDS * (size_t)(N + 1) + (size_t)4 * term_m);
-}
-
-template <int LPW, int WPB>
-static hipError_t launch_lanes_t(const DevCfg &cfg, const SolveArgs &a, double *ws, hipStream_t st)
-{
-    const int nblk = (a.B + LPW - 1) / LPW;
-    hipLaunchKernelGGL((k_mpc_lanes<LPW, WPB>), dim3((nblk + WPB - 1) / WPB), dim3(WPB * WAVE), 0, st, cfg, a, ws);
-    return hipGetLastError();
+    return ((size_t)B + lpw - 1) / lpw * lpw * ((size_t)lanes::LN_FIELDS * (size_t)(N + 1) + (size_t)4 * term_m);
 }
 
 // `Bcap` is the batch size the workspace was laid out for (the handle's capacity): it fixes the lanes per wave, so that
@@ -1077,14 +1131,14 @@ static hipError_t launch_lanes_t(const DevCfg &cfg, const SolveArgs &a, double *
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st)
 {
     if (cfg.kind == MPC_KIND_NL || a.mode == MODE_OFL || !ws) return hipErrorInvalidValue;
-    if (((size_t)(cfg.N + 1) * LN_FIELDS + (size_t)4 * a.term_m) * 64 * 8 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // a wave's block must fit a 32-bit byte offset
+    if (((size_t)(cfg.N + 1) * lanes::LN_FIELDS + (size_t)4 * a.term_m) * 64 * 8 >= ((size_t)1 << 31)) return hipErrorInvalidValue;   // a wave's block must fit a 32-bit byte offset
     if (a.term_m < 0 || (a.term_m > 0 && !a.term_C)) return hipErrorInvalidValue;
-    switch (lanes_per_wave((int)Bcap)) {
-    case 64: return launch_lanes_t<64, 1>(cfg, a, ws, st);
-    case 32: return launch_lanes_t<32, 1>(cfg, a, ws, st);
-    case 16: return launch_lanes_t<16, 1>(cfg, a, ws, st);
-    default: return launch_lanes_t<8, 1>(cfg, a, ws, st);
-    }
+    // px takes no part when nothing weighs it (a.px_free: stage weight zero and a zero first row and column of the
+    // terminal weight, in the controller's weights or in every row of the per-scenario cost table)
+    const bool nopx = a.px_free != 0;
+    const int lpw = lanes_per_wave((int)Bcap);
+    return nopx ? lanes_nopx::launch_variant(cfg, a, ws, lpw, st) : lanes::launch_variant(cfg, a, ws, lpw, st);
 }
+#endif
 
 }  // namespace mpc

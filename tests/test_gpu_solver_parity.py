@@ -198,13 +198,19 @@ def test_lpv_steps_that_once_broke_the_interior_point(orc80, golden):
         assert abs(u0[b] - u_ref) <= _tol(np.array([u_ref]))[0], (b, u0[b], u_ref, iters[b])
 
 
-@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("OFL", 80, 0.8), ("L", 7, 0.07), ("L", 128, 1.28)])
-def test_lane_layout_solve_matches_checker(orc80, kind, N, Tf):
+@pytest.mark.parametrize("kind,N,Tf,px_weight", [("L", 50, 0.5, 0.0), ("OFL", 80, 0.8, 0.0), ("L", 7, 0.07, 0.0), ("L", 128, 1.28, 0.0),
+                                                   ("L", 50, 0.5, 2.0), ("OFL", 30, 0.3, 0.5)])
+def test_lane_layout_solve_matches_checker(orc80, kind, N, Tf, px_weight):
     """The lane-per-scenario kernel (stage-wise Riccati interior point, no condensing) on the L / OFL problems, against
-    the checker: a second GPU algorithm for the same minimiser, next to the condensed wave-per-scenario kernels."""
+    the checker: a second GPU algorithm for the same minimiser, next to the condensed wave-per-scenario kernels.  With
+    the parameter files' weights nothing weighs the longitudinal position and the solver build without it runs; a
+    weight on it (px_weight, entry Q[0][0] of the parameter set) takes the general build."""
+    import copy
     import torch
     from oracle import oracle as O
-    from mpc_amd.controllers import LOcp, OFLOcp
+    from mpc_amd.controllers import LOcp, OFLOcp, read_parameters
+    params = copy.deepcopy(read_parameters("parameters_L.yaml"))
+    params["controller"]["Q"][0][0] = px_weight
     rng = np.random.default_rng(17)
     B = 40
     st = _scenarios(rng, B)
@@ -212,8 +218,9 @@ def test_lane_layout_solve_matches_checker(orc80, kind, N, Tf):
     st[2] = [15.0, 0.3, 1, 0, 8.0, 0, 0, 0.28]
     st[3] = [12.0, 0.0, 1, 0, 8.0, 0, 0, 0.0]          # on the line: unconstrained
     st[4] = [15.0, 0.2, 1, 0, 8.0, 0, 0, 0.32]         # start outside the steering bound: status 4 on both sides
-    cfg = O.make_cfg(kind, N, Tf)
-    ctl = (LOcp if kind == "L" else OFLOcp)(N, Tf, batch=B, solver_layout="lane")
+    cfg = O.make_cfg(kind, N, Tf, params=params)
+    ctl = (LOcp if kind == "L" else OFLOcp)(N, Tf, batch=B, solver_layout="lane", params=params)
+    assert (cfg[11] != 0.0) == (px_weight != 0.0)
     x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]
     wps, ps = [], []
     for s in st:
