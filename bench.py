@@ -90,12 +90,13 @@ def algorithmic_bytes(workload: str, N: int) -> float:
 
 def method_bytes(workload: str, N: int, mean_iters: float) -> float | None:
     """Workspace bytes the lane-per-scenario kernel streams per scenario-step (c3; the other kernels keep their problem in
-    registers and LDS): per stage and interior-point iteration its five sweeps read or write 206 doubles (step 44,
-    Riccati 36, affine forward 37, corrector backward 44, corrector forward 45); set-up of a step (stage model and
-    references written, free response, gradient scale, warm start or the unconstrained attempt) about 70."""
+    registers and LDS): per stage and interior-point iteration its five sweeps read or write 198 doubles (step 44,
+    Riccati 33, affine forward 36, corrector backward 41, corrector forward 44; the solver build without the longitudinal
+    position, which the workload's weights select); set-up of a step (stage model and references written, free
+    response, gradient scale, warm start or the unconstrained attempt) about 70."""
     if workload != "c3":
         return None
-    return 8.0 * N * (70 + 206 * mean_iters)
+    return 8.0 * N * (70 + 198 * mean_iters)
 
 
 def host_threads() -> int:
