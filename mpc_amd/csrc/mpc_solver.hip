@@ -122,10 +122,13 @@ template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STA
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
 constexpr int FIXED_WPB = 4;
 
-template <int N, bool GENERAL>
+// PULL: the work-queue form of the fixed-model kernel (fused launches); its own instantiation, so that the one-step
+// launches keep the straight-line body
+template <int N, bool GENERAL, bool PULL = false>
 __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(const DevCfg cfg,
                                                                                           const SolveArgs a)
 {
+    static_assert(!(GENERAL && PULL), "the work queue belongs to the fixed-model kernel");
     constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps scenario addressing scalar
     const int lane = threadIdx.x & 63;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     }
     // Work queue (fixed-model kernel, fused launches): the wave takes scenarios from `order` until none is left.  The
     // last wave to leave puts the two counters back to zero for the next launch.
-    const bool pull = !GENERAL && a.queue != nullptr;
+    constexpr bool pull = PULL;
 #pragma unroll 1
     for (;;) {
     if (pull) {
@@ -539,8 +542,9 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         const int ncomp = __builtin_popcount(a.sh_mask & 7);
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
         const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_area);
-        static bool lds_ok[MPC_MAX_DEVICES] = {};
-        if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false>), lds_ok)) return e;
+        static bool lds_ok[MPC_MAX_DEVICES] = {}, lds_ok_pull[MPC_MAX_DEVICES] = {};
+        if (hipError_t e = a.queue ? allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false, true>), lds_ok_pull)
+                                   : allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false, false>), lds_ok)) return e;
         int blocks = (a.B + FIXED_WPB - 1) / FIXED_WPB;
         if (a.queue) {
             // as many workgroups as stay resident (fewer when the batch is smaller): their waves share the whole batch
@@ -553,13 +557,14 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
             if (!cached_resident[slot] || cached_lds[slot] != lds) {
                 int per_cu = 0, cus = 0;
                 if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) return e;
-                if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_mpc<N, false>), FIXED_WPB * WAVE, lds)) return e;
+                if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_mpc<N, false, true>), FIXED_WPB * WAVE, lds)) return e;
                 cached_resident[slot] = per_cu * cus; cached_lds[slot] = lds;
             }
             const int resident = cached_resident[slot];
             if (resident >= 1 && resident < blocks) blocks = resident;
         }
-        hipLaunchKernelGGL((k_mpc<N, false>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
+        if (a.queue) hipLaunchKernelGGL((k_mpc<N, false, true>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
+        else hipLaunchKernelGGL((k_mpc<N, false, false>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
         const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36);
