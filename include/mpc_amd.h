@@ -86,7 +86,8 @@ typedef struct mpc_config {
     int solver_layout;   /* how scenarios map to the GPU (results agree to the solver tolerances, not bit for bit):
                           * MPC_LAYOUT_AUTO; MPC_LAYOUT_WAVE: one wavefront per scenario, horizon condensed into a dense
                           * N x N problem; MPC_LAYOUT_LANE: one lane per scenario, stage-wise Riccati interior point
-                          * (kinds L / OFL / LPV; not for mpc_ofl_closed_loop_run).  AUTO = LANE for MPC_KIND_LPV, else WAVE */
+                          * (kinds L / OFL / LPV; not for mpc_ofl_closed_loop_run).  AUTO = LANE where it is the faster one:
+                          * kinds L and LPV at horizons other than 10, 20, 30, 40, 50, 64 with B >= 2048; else WAVE */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

@@ -105,7 +105,8 @@ class _CondensedMpc:
         # the controller definition (utils/step_planning.py:51)
         self._step_ramp = float(step_ramp_length)
         # "wave": one wavefront per scenario on the condensed problem; "lane": one lane per scenario, stage-wise Riccati
-        # interior point; "auto": lane for the LPV controller, wave otherwise
+        # interior point; "auto": lane where it is the faster one (L / LPV at horizons without a register-resident wave
+        # kernel, from 2048 scenarios up), wave otherwise
         self._layout = _lib.LAYOUT[solver_layout]
         if terminal_set is not None and solver_layout == "auto":
             self._layout = _lib.LAYOUT["lane"]          # general terminal rows are handled by the stage-wise solver

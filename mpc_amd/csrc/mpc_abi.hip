@@ -128,7 +128,13 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (!h) return fail(nullptr, MPC_ENOMEM, "mpc_create: out of host memory");
     h->cfg = *cfg;
     h->px_free = weights_px_free(cfg->w, cfg->We);
-    h->lanes = cfg->solver_layout == MPC_LAYOUT_LANE || (cfg->solver_layout == MPC_LAYOUT_AUTO && cfg->kind == MPC_KIND_LPV);
+    // AUTO: the lane layout where it is the faster one (measured, closed-loop skidpad runs): horizons without a
+    // register-resident wave kernel from 2048 scenarios up (L at N = 80: 1.5 against 0.8 M scenario-steps/s at 4096
+    // scenarios, 2.7 against 0.8 M at 8192; below 2048 scenarios a wavefront per scenario has the shorter step).  At the
+    // instantiated horizons the wave kernels win at every batch size (LPV at N = 50: 6.9 against 4.4 M at 8192).
+    h->lanes = cfg->solver_layout == MPC_LAYOUT_LANE ||
+               (cfg->solver_layout == MPC_LAYOUT_AUTO && (cfg->kind == MPC_KIND_LPV || cfg->kind == MPC_KIND_L) &&
+                !mpc::horizon_templated(cfg->N) && cfg->B >= 2048);
     fill_devcfg(cfg, h->dev);
     DeviceScope scope(cfg->device);
     hipError_t e = scope.err;

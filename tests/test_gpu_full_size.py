@@ -18,6 +18,8 @@ def _build(name, st, mp=None):
     from mpc_amd.batched import SkidpadBatch
     w = bench.WORKLOADS[name]
     kw = dict(sqp_tol=1e-30, sqp_max_iter=3) if name == "c5" else {}
+    if name == "c3":
+        kw["solver_layout"] = "lane"      # what the full batch gets by itself; the small batch must run the same solver
     sim = SkidpadBatch(w["N"], w["Tf"], st, model=w["kind"], **kw)
     if mp is not None:
         sim.ocp.set_model_params(mp)
