@@ -79,8 +79,13 @@ class _CondensedMpc:
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
                  ipm_warm_start: bool = True, step_ramp_length: float = 0.0, solver_layout: str = "auto",
                  terminal_set=None, _host_only: bool = False):
-        if not discrete:
-            raise NotImplementedError("only the discrete (forward-Euler) model of the reference is implemented")
+        if not discrete and self.kind != "LPV":
+            # The reference's constructors do not get past their own stability analysis with discrete=False: that
+            # branch keeps the 6x6 continuous-time A next to the 5x5 Q (LMPC2.py:370-382,406,411; OFLMPC2.py:389-402,
+            # 424,429) and control.ctrb raises ValueError on the shapes, before any solver exists. The LPV controller
+            # stores the flag and never reads it (LPVMPC.py:33), so there it changes nothing.
+            raise ValueError("discrete=False: the reference's constructor fails here as well (6x6 continuous A against "
+                             "the 5x5 Q in its stability analysis); only the forward-Euler model exists")
         log.setLevel(logging.DEBUG if debug else logging.INFO)
         self.params = read_parameters(self.param_file, params)
         self.discrete = discrete

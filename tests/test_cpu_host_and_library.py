@@ -170,3 +170,16 @@ def test_measurement_model_matches_reference_recording(golden):
     ref = np.array([b.measure_state_noise(np.zeros(10)) for _ in range(3)])
     np.testing.assert_allclose(lit[:, 0], ref, rtol=0, atol=1e-15)
     assert a.measurement_noise(4, 5).shape == (4, 5, 7)
+
+
+def test_discrete_flag_behaves_like_the_reference_constructors():
+    """LMPC2.py:370-411 / OFLMPC2.py:389-429: with discrete=False the stability analysis pairs the 6x6 continuous A with
+    the 5x5 Q and control.ctrb raises ValueError, so no L / OFL controller can be built that way; LPVMPC.py:33 stores
+    the flag and never reads it."""
+    from mpc_amd.controllers import LOcp, OFLOcp, LPVOcp
+    for cls in (LOcp, OFLOcp):
+        with pytest.raises(ValueError):
+            cls(10, 0.1, discrete=False, _host_only=True)
+    a = LPVOcp(10, 0.1, discrete=False, _host_only=True)
+    b = LPVOcp(10, 0.1, _host_only=True)
+    assert a.discrete is False and np.array_equal(a.W, b.W) and np.array_equal(a.W_e, b.W_e)
