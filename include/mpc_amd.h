@@ -54,6 +54,9 @@ extern "C" {
 #define MPC_LAYOUT_WAVE 1
 #define MPC_LAYOUT_LANE 2
 
+#define MPC_QP_AUTO 0            /* active-set solve first where the fixed-model cache is on, interior point otherwise */
+#define MPC_QP_INTERIOR_POINT 1  /* interior point for every constrained solve */
+
 /* Controller definition; what the reference's constructors derive from parameters_*.yaml
  * (LMPC2.py:14-96, LPVMPC.py:10-92, OFLMPC2.py:16-100). */
 typedef struct mpc_config {
@@ -88,6 +91,13 @@ typedef struct mpc_config {
                           * N x N problem; MPC_LAYOUT_LANE: one lane per scenario, stage-wise Riccati interior point
                           * (kinds L / OFL / LPV; not for mpc_ofl_closed_loop_run).  AUTO = LANE where it is the faster one:
                           * kinds L and LPV at horizons other than 10, 20, 30, 40, 50, 64 with B >= 2048; else WAVE */
+    int qp_method;       /* how a solve whose unconstrained minimiser violates a bound is finished.  MPC_QP_AUTO: with the
+                          * fixed-model cache on (mpc_condense_fixed) the active bounds are found by a primal-dual active-set
+                          * iteration started from the previous closed-loop step's set and the multipliers come from a small
+                          * system built from the cached inv(H); the result is certified by its KKT residual, and whatever
+                          * does not end that way (large or cycling sets) goes to the interior point.  Both give the unique
+                          * minimiser (they agree to the solver tolerances, not bit for bit).
+                          * MPC_QP_INTERIOR_POINT: interior point only */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
@@ -264,7 +274,11 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream);
 /* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
  * copied to a host array of 16 doubles after synchronising the stream:
  *   [0] scenarios, [1] sum iterations, [2] count status != 0, [3] count constrained solves,
- *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual, [8] sum of SQP iterations (MPC_KIND_NL); rest reserved. */
+ *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual, [8] sum of SQP iterations (MPC_KIND_NL),
+ *   [9] constrained solves finished by the active-set method, [10] sum of its iterations, [11] solves it handed to the
+ *   interior point because the active set outgrew its capacity or was rank-deficient, [12] because its iteration did not
+ *   settle or its result did not certify; rest reserved.
+ *   [1] counts interior-point iterations only. */
 int mpc_get_stats(mpc_handle *h, void *stream, double *host16);
 
 #ifdef __cplusplus

@@ -44,10 +44,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
 
+    # developer builds: MPC_DEV_HORIZONS="50" instantiates the register-resident kernels for that horizon only (a full
+    # build takes minutes); MPC_DEV_DEFINES="-DNAME=VALUE ..." adds macros.  Never set for a build that is shipped.
+    dev = []
+    if os.environ.get("MPC_DEV_HORIZONS"):
+        hs = " ".join(f"X({int(n)})" for n in os.environ["MPC_DEV_HORIZONS"].split(","))
+        dev.append(f"-DMPC_HORIZONS(X)={hs}")
+    dev += os.environ.get("MPC_DEV_DEFINES", "").split()
+
     def compile_one(job):
         src, objname, extra = job
         obj = os.path.join(objdir, objname)
-        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + dev + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

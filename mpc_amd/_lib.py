@@ -13,6 +13,7 @@ KIND = {"L": 0, "OFL": 1, "LPV": 2, "NL": 3}
 PLANNER_SKIDPAD, PLANNER_STEP = 0, 1
 MAX_HORIZON = 128
 LAYOUT = {"auto": 0, "wave": 1, "lane": 2}
+QP_METHOD = {"auto": 0, "interior_point": 1}
 
 
 class MpcConfig(C.Structure):
@@ -23,7 +24,7 @@ class MpcConfig(C.Structure):
         ("tol_res", C.c_double), ("max_iter", C.c_int), ("lpv_lin_prev", C.c_int),
         ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
         ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int), ("step_ramp_length", C.c_double),
-        ("solver_layout", C.c_int),
+        ("solver_layout", C.c_int), ("qp_method", C.c_int),
     ]
 
 
@@ -64,7 +65,9 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    """The in-tree library, or the one MPC_AMD_LIBRARY names (a prebuilt libmpc_amd.so kept elsewhere, e.g. an earlier
+    build for an A/B measurement)."""
+    return os.environ.get("MPC_AMD_LIBRARY") or _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:

@@ -78,7 +78,7 @@ class _CondensedMpc:
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
                  ipm_warm_start: bool = True, step_ramp_length: float = 0.0, solver_layout: str = "auto",
-                 terminal_set=None, _host_only: bool = False):
+                 terminal_set=None, qp_method: str = "auto", _host_only: bool = False):
         if not discrete and self.kind != "LPV":
             # The reference's constructors do not get past their own stability analysis with discrete=False: that
             # branch keeps the 6x6 continuous-time A next to the 5x5 Q (LMPC2.py:370-382,406,411; OFLMPC2.py:389-402,
@@ -113,6 +113,9 @@ class _CondensedMpc:
         # interior point; "auto": lane where it is the faster one (L / LPV at horizons without a register-resident wave
         # kernel, from 2048 scenarios up), wave otherwise
         self._layout = _lib.LAYOUT[solver_layout]
+        # "auto": constrained solves of the fixed-model path go through the active-set method first (interior point where
+        # it does not end at the minimiser); "interior_point": interior point only
+        self._qp_method = _lib.QP_METHOD[qp_method]
         if terminal_set is not None and solver_layout == "auto":
             self._layout = _lib.LAYOUT["lane"]          # general terminal rows are handled by the stage-wise solver
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
@@ -178,6 +181,7 @@ class _CondensedMpc:
         cfg.ipm_cold_start = self._ipm_cold
         cfg.step_ramp_length = self._step_ramp
         cfg.solver_layout = self._layout
+        cfg.qp_method = self._qp_method
         return cfg
 
     def stability(self):
@@ -322,8 +326,9 @@ class _CondensedMpc:
         rc = self.solver._lib.mpc_get_stats(self.solver.h, _dev.stream_ptr(self.device), _lib.hptr(out))
         _lib.check(rc, self.solver.h, "mpc_get_stats")
         keys = ["scenarios", "sum_iterations", "n_status_nonzero", "n_constrained", "sum_abs_u0", "max_abs_u0",
-                "max_complementarity", "max_residual", "sum_sqp_iterations"]
-        return dict(zip(keys, out[:9]))
+                "max_complementarity", "max_residual", "sum_sqp_iterations", "n_active_set_solves",
+                "sum_active_set_iterations", "n_active_set_too_large", "n_active_set_unsettled"]
+        return dict(zip(keys, out[:13]))
 
 
 class LOcp(_CondensedMpc):

@@ -27,6 +27,8 @@ struct mpc_handle {
     bool px_free = false;        // nothing weighs the longitudinal position (controller weights, or every row of cost_scen)
     double *stats16 = nullptr;   // device result of the statistics reduction
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
+    double *sh_T = nullptr;      // table of the active-set solve (part of the cache; NULL with qp_method = interior point)
+    int *as2 = nullptr;          // B * 4: active-set counters of the last call (SolveArgs::as_out)
     double sh_vx = 0.0;
     int sh_mask = 0;
     bool sh_on = false, sh_exclusive = false;
@@ -96,6 +98,7 @@ static const char *check_config(const mpc_config *cfg)
     } else if (!(cfg->w[6] > 0.0)) return "input weight R*r must be positive (strict convexity)";
     if (cfg->solver_layout < MPC_LAYOUT_AUTO || cfg->solver_layout > MPC_LAYOUT_LANE) return "unknown solver_layout";
     if (cfg->solver_layout == MPC_LAYOUT_LANE && cfg->kind == MPC_KIND_NL) return "the NL controller has no lane-per-scenario kernel";
+    if (cfg->qp_method < MPC_QP_AUTO || cfg->qp_method > MPC_QP_INTERIOR_POINT) return "unknown qp_method";
     if (!(cfg->max_rate > 0.0) || !(cfg->max_steering > 0.0)) return "max_rate and max_steering must be positive";
     return nullptr;
 }
@@ -156,6 +159,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->as2, B * 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->as2, 0, B * 4 * sizeof(int));
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "mpc_create: workspace allocation");
         mpc_destroy(h);
@@ -171,7 +176,7 @@ void mpc_destroy(mpc_handle *h)
     DeviceScope scope(h->cfg.device);
     (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
-    (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
+    (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T); (void)hipFree(h->as2);
     (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
     delete h;
 }
@@ -250,17 +255,19 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
     // the cache belongs to the register-resident kernels; other horizons keep condensing per scenario (same results)
     if (!mpc::horizon_templated(h->cfg.N)) { h->sh_on = false; return MPC_OK; }
     const size_t N = (size_t)h->cfg.N;
-    if (!h->sh_H) {      // all three buffers or none: a partial set would hand the kernels a null pointer on the next call
+    const bool want_T = h->cfg.qp_method != MPC_QP_INTERIOR_POINT;
+    if (!h->sh_H) {      // all buffers or none: a partial set would hand the kernels a null pointer on the next call
         hipError_t e = hipMalloc(&h->sh_H, N * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(&h->sh_Kref, 3 * N * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc(&h->sh_Kx, 5 * N * sizeof(double));
+        if (e == hipSuccess && want_T) e = hipMalloc(&h->sh_T, 4 * N * N * sizeof(double));
         if (e != hipSuccess) {
-            (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx);
-            h->sh_H = h->sh_Kref = h->sh_Kx = nullptr; h->sh_on = false;
+            (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T);
+            h->sh_H = h->sh_Kref = h->sh_Kx = h->sh_T = nullptr; h->sh_on = false;
             return hip_fail(h, e, "mpc_condense_fixed: cache allocation");
         }
     }
-    HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, (hipStream_t)stream));
+    HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, h->sh_T, (hipStream_t)stream));
     h->sh_vx = vx;
     h->sh_mask = 0;
     for (int c = 0; c < 3; c++) {
@@ -277,7 +284,9 @@ static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
 {
     if (h->sh_on && !h->mp_scen && !h->cost_scen) {
         a.sh_H = h->sh_H; a.sh_Kref = h->sh_Kref; a.sh_Kx = h->sh_Kx; a.sh_vx = h->sh_vx; a.sh_mask = h->sh_mask; a.sh_exclusive = h->sh_exclusive ? 1 : 0;
+        a.sh_T = h->sh_T;
     }
+    a.as_out = h->as2;
 }
 
 static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStream_t st)
@@ -492,7 +501,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
     if (!h || !host16) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
     ON_HANDLE_DEVICE(h);
-    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->stats16));
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->as2, h->stats16));
     HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     return MPC_OK;

@@ -1,0 +1,362 @@
+// Active-set solve of the condensed MPC problem in the space of the multipliers (gfx950, wave64), for the fixed-model
+// kernels: the problem's Hessian H is the same for every scenario and step, so inv(H) and its products with the
+// steering rows are condensed once (k_condense_fixed) and a solve works on the few active bounds only.
+//
+//   min 1/2 U'HU + g'U   s.t.  |u_i| <= umax,  lo_k <= dt * sum_{j<=k} u_j <= up_k        (LMPC2.py:196-260)
+//
+// With the unconstrained minimiser Uu = -inv(H) g and an active set of m bounds  E U = b  (rows of E: a unit row for an
+// input bound, dt * prefix-sum row for a steering bound), the minimiser on that set is
+//   U = Uu - inv(H) E' nu,     (E inv(H) E') nu = E Uu - b,
+// an m x m positive definite system whose entries are read from the table T = [I; P] inv(H) [I P'] (P = the steering
+// rows), 2N x 2N, symmetric.  The set is found by exchanging bounds (per iteration the bound whose multiplier has the
+// wrong sign by the most leaves, the bound the new point violates by the most enters) started from the previous
+// closed-loop step's set moved one stage ahead; when nothing is left to exchange the KKT conditions hold, i.e. U is
+// the unique minimiser.  The result is then certified
+// with H itself (Newton correction of the point on its set, computed from the Hessian, not from its inverse) and
+// refined through the same factorisation.  Whatever does not end that way within a few iterations (sets larger than
+// the capacity, a cycling iteration) is left to the interior point.
+#pragma once
+#include <utility>
+#include "mpc_wave.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace mpc {
+
+typedef __attribute__((address_space(1))) double aset_gdouble;
+typedef __attribute__((address_space(3))) double aset_ldouble;
+typedef __attribute__((address_space(3))) int aset_lint;
+
+// iteration caps (counted over the whole solve): an iteration of the largest size class costs about as much as one of
+// the interior point, so a set of that size that has not settled after a few exchanges is handed on
+constexpr int ASET_MAX_ITER = 10;
+__device__ __forceinline__ constexpr int aset_iter_cap(int MM) { return MM <= 32 ? 10 : 6; }
+constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a previous set starts from
+// sizes of the certificate's corrections relative to the input bound: a first correction below EARLY is taken as final
+// (what is left after it is smaller by the accuracy of the cached inverse), a later one has to come out below TOL
+#ifndef ASET_DU_EARLY
+#define ASET_DU_EARLY 0.0
+#endif
+constexpr double ASET_DU_TOL = 1e-10;
+// A pivot below this fraction of the row's own diagonal entry: the bound's row depends on the rows before it
+constexpr double ASET_PIV_MIN = 1e-9;
+
+// The multiplier system is solved in one of three sizes (straight-line code each, rows beyond the set are unit rows)
+template <int N> constexpr int aset_class(int i) { return i == 0 ? 16 : i == 1 ? (2 * N < 32 ? 2 * N : 32) : (2 * N < 64 ? 2 * N : 64); }
+// LDS the solve borrows from the wave's area: the list of active bounds (ints) and one list of doubles
+template <int N> constexpr int aset_lds_doubles() { return aset_class<N>(2) / 2 + aset_class<N>(2); }
+
+// LDL' of an MM x MM matrix, row r in the registers of lane r (statically indexed), the pivot column broadcast through
+// v_readlane.  A step whose pivot shows that the row depends on the rows before it is skipped: the multiplier of that
+// row comes out as zero and the lane is left with dinv = 0 as the mark.
+template <int MM>
+struct SmallLdl {
+    double row[MM];
+    double dinv;
+
+    template <int K>
+    __device__ __forceinline__ void eliminate(int lane, double diag)
+    {
+        const double c = row[K];
+        const double piv = bcast(c, K);
+        const double inv = piv > ASET_PIV_MIN * bcast(diag, K) ? fast_rcp(piv) : 0.0;
+        const bool below = lane > K;
+        const double l = below ? c * inv : 0.0;
+        if (lane == K) dinv = inv;
+#pragma unroll
+        for (int j0 = K + 1; j0 < MM; j0 += 4) {
+            double cj[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (j0 + g < MM) cj[g] = bcast_pinned(c, j0 + g);
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (j0 + g < MM) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (below) row[K] = l;
+    }
+
+    template <int... Ks>
+    __device__ __forceinline__ void eliminate_all(int lane, double diag, std::integer_sequence<int, Ks...>)
+    {
+        (eliminate<Ks>(lane, diag), ...);
+    }
+
+    __device__ __forceinline__ void factor(int lane_in, double diag)
+    {
+        dinv = 1.0;
+        eliminate_all(opaque_int(lane_in), diag, std::make_integer_sequence<int, MM>{});
+    }
+
+    __device__ __forceinline__ double solve(double b, int lane_in) const
+    {
+        const int lane = opaque_int(lane_in);
+        double w = b;
+#pragma unroll
+        for (int k = 0; k < MM - 1; k++) {
+            const double t = fma(-row[k], bcast(w, k), w);
+            w = lane > k ? t : w;
+        }
+#pragma unroll
+        for (int k = MM - 1; k > 0; k--) {
+            const double t = fma(-row[k], bcast(w * dinv, k), w);
+            w = lane < k ? t : w;
+        }
+        return w * dinv;
+    }
+};
+
+enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 };
+
+struct AsetResult {
+    double U;          // the minimiser (this lane's input), valid when why == ASET_SOLVED
+    int au, ad;        // this lane's input / steering bound in the set: +1 upper, -1 lower, 0 none
+    int iters;         // active-set iterations spent so far
+    int why;           // ASET_SOLVED, or handed on: GROW the set outgrew this size class, UNSETTLED the iteration did not
+                       // settle within ASET_MAX_ITER, UNCERTIFIED the corrections of the certificate stayed too large
+};
+
+// The iteration in one size class, from the set (au, ad) and iteration count `it0`.  Uu: this lane's unconstrained
+// minimiser (0 beyond the horizon), vdu = dt * prefix sum of Uu; up_d / lo_d: this lane's steering bounds
+// (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
+// ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
+// written with the result when the solve succeeds (or NULL); lds: aset_lds_doubles<N>() doubles of this wave.
+// Not inlined, like the interior point: the registers of a size class (the row of its multiplier system) stay out of the
+// per-step path's allocation, and the smallest class, which serves most solves, saves and restores few of them.  TAG
+// gives every calling kernel its own copies with that kernel's register budget.
+template <int N, int MM>
+__device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
+                                                double up_d, double lo_d, double umax, double dmax, double dt,
+                                                double *rec, int au, int ad, int it0, double *lds)
+{
+    constexpr unsigned LD = 2 * N;                       // row length of T
+    const bool valid = lane < N, validd = lane < N - 1;
+    const unsigned lc = valid ? lane : 0;
+    aset_lint *cid_l = (aset_lint *)lds;
+    aset_ldouble *val_l = (aset_ldouble *)(lds + aset_class<N>(2) / 2);
+    const aset_gdouble *Tg = (const aset_gdouble *)T;
+    const aset_gdouble *Hg = (const aset_gdouble *)Hm;
+    const double tol_u = 1e-12 * umax, tol_d = 1e-12 * dmax;
+
+    SmallLdl<MM> ldl;
+    AsetResult out = {0.0, au, ad, it0, ASET_UNSETTLED};
+    double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0;
+    int my_cid = 0, m = 0, rank_u = 0, rank_d = 0;
+    bool converged = false;
+#pragma unroll 1
+    for (int it = it0; it < aset_iter_cap(MM); it++) {
+        const unsigned long long mask_u = __ballot(au != 0), mask_d = __ballot(ad != 0);
+        const int m_u = __popcll(mask_u);
+        m = m_u + __popcll(mask_d);
+        if (m > MM) { out.au = au; out.ad = ad; out.iters = it; out.why = ASET_GROW; return out; }
+        out.iters = it + 1;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        rank_u = __popcll(mask_u & below);
+        rank_d = m_u + __popcll(mask_d & below);
+        // the active bounds in lanes 0..m-1: which bound, and by how much the unconstrained minimiser misses it
+        if (au != 0) { cid_l[rank_u] = lane; val_l[rank_u] = Uu - (au > 0 ? umax : -umax); }
+        if (ad != 0) { cid_l[rank_d] = N + lane; val_l[rank_d] = vdu - (ad > 0 ? up_d : lo_d); }
+        wave_sync();
+        const bool act = lane < m;
+        my_cid = act ? cid_l[lane] : 0;
+        const double my_d = act ? val_l[lane] : 0.0;
+        wave_sync();
+        // row `lane` of E inv(H) E', gathered from the table; lanes and columns beyond the set form a unit matrix
+        const unsigned rowoff = (unsigned)my_cid * LD;
+        const double diag0 = act ? Tg[rowoff + (unsigned)my_cid] : 1.0;
+        const int lane_o = opaque_int(lane);
+#pragma unroll
+        for (int s = 0; s < MM; s++) {
+            const int cs = __builtin_amdgcn_readlane(my_cid, s);
+            const double t = (Tg + cs)[rowoff];
+            ldl.row[s] = (act && s < m) ? t : (lane_o == s ? 1.0 : 0.0);
+        }
+        ldl.factor(lane, diag0);
+        nu = ldl.solve(my_d, lane);
+        // a bound whose row depends on the rows before it (an input run that already fixes a steering row, ...) was left
+        // out of the system: it leaves the set here (not-a-number fails the sign test below) and comes back if violated
+        if (act) val_l[lane] = ldl.dinv == 0.0 ? __builtin_nan("") : nu;
+        wave_sync();
+        nu_u = au != 0 ? val_l[rank_u] : 0.0;
+        nu_d = ad != 0 ? val_l[rank_d] : 0.0;
+        wave_sync();
+        // U = Uu - sum_s nu_s * (column of inv(H) [I P'] of bound s)
+        double acc0 = Uu, acc1 = 0.0;
+#pragma unroll 1
+        for (int s = 0; s < m; s += 2) {
+            const int c0 = __builtin_amdgcn_readlane(my_cid, s);
+            const int c1 = __builtin_amdgcn_readlane(my_cid, min(s + 1, m - 1));
+            const double t0 = (Tg + (unsigned)c0 * LD)[lc], t1 = (Tg + (unsigned)c1 * LD)[lc];
+            const double n0 = bcast(nu, s), n1 = (s + 1 < m) ? bcast(nu, min(s + 1, m - 1)) : 0.0;
+            acc0 = fma(-n0, t0, acc0);
+            acc1 = fma(-n1, t1, acc1);
+        }
+        U = valid ? acc0 + acc1 : 0.0;
+        const double vd = dt * incl_prefix(U, lane);
+        // next set: the one bound whose multiplier has the wrong sign by the most (or whose row was left out) goes, the
+        // one bound the new point violates by the most comes in.  (Exchanging every such bound at once is quicker when
+        // it settles, but from a set that is off by a stage at the end of a run it throws out half the run and cycles.)
+        const bool bad_u = au != 0 && !(nu_u * (double)au >= 0.0), bad_d = ad != 0 && !(nu_d * (double)ad >= 0.0);
+        const double sc_u = bad_u ? (nu_u != nu_u ? 1e300 : fabs(nu_u) * umax) : -1.0;
+        const double sc_d = bad_d ? (nu_d != nu_d ? 1e300 : fabs(nu_d) * dmax) : -1.0;
+        const double worst = wave_max(fmax(sc_u, sc_d));
+        const double vi_u = (au == 0 && valid) ? (fabs(U) - umax - tol_u) / umax : -1.0;
+        const double vi_d = (ad == 0 && validd) ? (fmax(vd - up_d, lo_d - vd) - tol_d) / dmax : -1.0;
+        const double most = wave_max(fmax(vi_u, vi_d));
+        if (!(worst >= 0.0) && !(most > 0.0)) { converged = true; break; }
+        if (worst >= 0.0) {
+            const unsigned long long cu = __ballot(sc_u == worst), cd = __ballot(sc_d == worst);
+            if (cu) { if (lane == __ffsll((long long)cu) - 1) au = 0; }
+            else if (lane == __ffsll((long long)cd) - 1) ad = 0;
+        }
+        if (most > 0.0) {
+            const unsigned long long cu = __ballot(vi_u == most), cd = __ballot(vi_d == most);
+            if (cu) { if (lane == __ffsll((long long)cu) - 1) au = U > 0.0 ? 1 : -1; }
+            else if (lane == __ffsll((long long)cd) - 1) ad = vd > up_d ? 1 : -1;
+        }
+    }
+    out.au = au; out.ad = ad;
+    if (!converged) return out;
+    out.why = ASET_UNCERTIFIED;
+
+    // Certificate from H itself: the Newton correction of the point on its active set, computed from the residual of
+    // H U + g + E' nu (the Hessian, not its cached inverse), through the factorisation at hand:
+    //   r = H (U - Uu) + E' nu,  z = inv(H) r,  w = inv(S) (E z - (E U - b)),  nu -= w,  U += -z + inv(H) E' w.
+    // The size of the correction is the error of the point it is applied to.
+    bool certified = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 3 && !certified; pass++) {
+        const double dU = valid ? U - Uu : 0.0;
+        double hu0 = 0.0, hu1 = 0.0;
+#pragma unroll 10
+        for (int j = 0; j < N; j += 2) {
+            hu0 = fma(Hg[j * N + lc], bcast(dU, j), hu0);
+            if (j + 1 < N) hu1 = fma(Hg[(j + 1) * N + lc], bcast(dU, j + 1), hu1);
+        }
+        const double frc = nu_u + dt * incl_suffix(validd ? nu_d : 0.0, lane);      // (E' nu)[lane]
+        const double r = valid ? hu0 + hu1 + frc : 0.0;
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll 10
+        for (int j = 0; j < N; j += 2) {
+            z0 = fma(Tg[j * LD + lc], bcast(r, j), z0);
+            if (j + 1 < N) z1 = fma(Tg[(j + 1) * LD + lc], bcast(r, j + 1), z1);
+        }
+        const double z = valid ? z0 + z1 : 0.0;
+        const double pz = dt * incl_prefix(z, lane);
+        const double vdc = dt * incl_prefix(valid ? U : 0.0, lane);
+        // right-hand side E z - (E U - b): the correction also closes what the point misses its active bounds by
+        if (au != 0) val_l[rank_u] = z - (U - (au > 0 ? umax : -umax));
+        if (ad != 0) val_l[rank_d] = pz - (vdc - (ad > 0 ? up_d : lo_d));
+        wave_sync();
+        const double ez = lane < m ? val_l[lane] : 0.0;
+        wave_sync();
+        const double dn = ldl.solve(ez, lane);
+        if (lane < m) val_l[lane] = dn;
+        wave_sync();
+        if (au != 0) nu_u -= val_l[rank_u];
+        if (ad != 0) nu_d -= val_l[rank_d];
+        wave_sync();
+        double c0a = -z, c1a = 0.0;
+#pragma unroll 1
+        for (int s = 0; s < m; s += 2) {
+            const int c0 = __builtin_amdgcn_readlane(my_cid, s);
+            const int c1 = __builtin_amdgcn_readlane(my_cid, min(s + 1, m - 1));
+            const double t0 = (Tg + (unsigned)c0 * LD)[lc], t1 = (Tg + (unsigned)c1 * LD)[lc];
+            const double n0 = bcast(dn, s), n1 = (s + 1 < m) ? bcast(dn, min(s + 1, m - 1)) : 0.0;
+            c0a = fma(n0, t0, c0a);
+            c1a = fma(n1, t1, c1a);
+        }
+        const double corr = valid ? c0a + c1a : 0.0;
+        U += corr;
+        const double cmax = wave_max(fabs(corr));
+        certified = cmax <= (pass == 0 ? ASET_DU_EARLY : ASET_DU_TOL) * umax;
+    }
+    if (!certified) return out;
+    // the refined point against the bounds and the signs once more, at the accuracy of the certificate
+    {
+        const double force = nu_u + dt * incl_suffix(validd ? nu_d : 0.0, lane);
+        const double scale = fmax(1.0, wave_max(fabs(valid ? force : 0.0)));
+        const double vd = dt * incl_prefix(valid ? U : 0.0, lane);
+        bool good = true;
+        if (valid) good = fabs(U) <= umax * (1.0 + 1e-11) && nu_u * (double)au >= -1e-11 * scale;
+        if (validd) good = good && vd <= up_d + 1e-11 * dmax && vd >= lo_d - 1e-11 * dmax && nu_d * (double)ad >= -1e-11 * scale;
+        if (!__all(good)) return out;
+    }
+    U = valid ? fmin(fmax(U, -umax), umax) : 0.0;
+    if (rec && valid) {
+        aset_gdouble *w = (aset_gdouble *)rec;
+        w[lane] = U;
+        w[WAVE + lane] = au > 0 ? fmax(nu_u, 0.0) : 0.0;
+        w[2 * WAVE + lane] = au < 0 ? fmax(-nu_u, 0.0) : 0.0;
+        w[3 * WAVE + lane] = ad > 0 ? fmax(nu_d, 0.0) : 0.0;
+        w[4 * WAVE + lane] = ad < 0 ? fmax(-nu_d, 0.0) : 0.0;
+    }
+    out.U = U; out.why = ASET_SOLVED;
+    return out;
+}
+
+// The three size classes as functions of their own, each held to the registers its system needs (the attribute takes a
+// literal): what a function uses of the callee-saved registers it saves and restores on every call.
+#define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
+                      double dmax, double dt, double *rec, int au, int ad, int it0, double *lds
+#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, lds
+template <int N, int MM, int TAG>
+static __device__ __noinline__ AsetResult aset_run_small(MPC_ASET_ARGS)
+{
+    return aset_body<N, MM>(MPC_ASET_PASS);
+}
+template <int N, int MM, int TAG>
+static __device__ __noinline__ AsetResult aset_run_medium(MPC_ASET_ARGS)
+{
+    return aset_body<N, MM>(MPC_ASET_PASS);
+}
+template <int N, int MM, int TAG>
+static __device__ __noinline__ AsetResult aset_run_large(MPC_ASET_ARGS)
+{
+    return aset_body<N, MM>(MPC_ASET_PASS);
+}
+#undef MPC_ASET_ARGS
+#undef MPC_ASET_PASS
+
+// One solve: the starting set (the previous step's set one stage ahead when rec_valid, else what the unconstrained
+// minimiser violates), then the iteration in the smallest size class that holds the set, moving up a class when the set
+// outgrows it.  Arguments as aset_body.
+template <int N, int TAG>
+__device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
+                                                       double up_d, double lo_d, double umax, double dmax, double dt,
+                                                       double *rec, bool rec_valid, double *lds)
+{
+    constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2);
+    const bool valid = lane < N, validd = lane < N - 1;
+    int au = 0, ad = 0;
+    if (rec_valid) {
+        const aset_gdouble *w = (const aset_gdouble *)rec;
+        const int lc = valid ? lane : 0;
+        const int ln = min(lc + 1, N - 1), lnd = min(lc + 1, N - 2);
+        const double a0 = w[WAVE + ln], a1 = w[2 * WAVE + ln], a2 = w[3 * WAVE + lnd], a3 = w[4 * WAVE + lnd];
+        au = a0 > 0.0 ? 1 : (a1 > 0.0 ? -1 : 0);
+        ad = a2 > 0.0 ? 1 : (a3 > 0.0 ? -1 : 0);
+    } else {
+        au = Uu > umax ? 1 : (Uu < -umax ? -1 : 0);
+        ad = vdu > up_d ? 1 : (vdu < lo_d ? -1 : 0);
+    }
+    if (!valid) au = 0;
+    if (!validd) ad = 0;
+    wave_sync();                                         // the borrowed LDS area is still being read as something else
+    AsetResult r = {0.0, au, ad, 0, ASET_GROW};
+    int m = __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0));
+    if (!rec_valid && m > ASET_COLD_MAX) return r;       // a large violated set says little about the active one
+    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+    if (C1 > C0 && r.why == ASET_GROW) {
+        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+    }
+    if (C2 > C1 && r.why == ASET_GROW) {
+        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+    }
+    return r;
+}
+
+}  // namespace mpc

@@ -65,6 +65,9 @@ struct SolveArgs {
     const double *sh_H;      // [N][N] condensed Hessian
     const double *sh_Kref;   // [3][N][N]: inv(H) * d g / d ref_c(stage k+1), stored [c][k][i]
     const double *sh_Kx;     // [5][N]: -inv(H) * g for unit vy, r, delta, the constant term, unit d_hat
+    const double *sh_T;      // [2N][2N]: [I; P] inv(H) [I P'], P = the steering rows (active-set solve; NULL: interior point only)
+    int *as_out;             // [B][4]: active-set solves that ended at the minimiser, active-set iterations, solves handed to the
+                             // interior point because the set was too large or rank-deficient / did not settle or certify (or NULL)
     double sh_vx;
     int sh_exclusive;        // caller promises every scenario runs at sh_vx: launch the fixed-model-only kernel
     int sh_mask;             // bit c set: reference component c (x, y, sin psi) carries weight
@@ -96,7 +99,7 @@ hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 // lanes_workspace_doubles(N, Bcap) doubles laid out for a capacity of Bcap scenarios, and keeps the warm-start record between calls
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st);
 size_t lanes_workspace_doubles(int N, int B, int term_m);
-hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st);
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st);
 bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
 bool horizon_templated(int N);    // has a register-resident instantiation (and with it the fixed-model cache)
 
@@ -124,6 +127,6 @@ hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shif
 hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, const double *eig, const double *A,
                              const double *B, const double *K, double umax, const double *c, int *ok_out);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
-                        double *out16);
+                        const int *as2, double *out16);
 
 }  // namespace mpc

@@ -6,9 +6,11 @@
 //   2. linearises/discretises the controller model per stage,
 //   3. condenses the OCP into  min 1/2 U'HU + g'U,  |u_k| <= umax,  |delta_0 + dt*sum_{j<=k} u_j| <= dmax
 //      (per scenario, or through the fixed-model cache when every stage runs at one cached speed),
-//   4. solves it exactly: unconstrained minimiser first, Mehrotra predictor-corrector interior point only if a
-//      bound is violated; every Newton system K = H + A'DA is factorised K = L D L' with row k of K held in
-//      the registers of lane k and the pivot column broadcast through v_readlane,
+//   4. solves it exactly: unconstrained minimiser first; if a bound is violated, on the fixed-model path an active-set
+//      solve in the space of the multipliers (mpc_aset.hpp), and where that does not end at the minimiser, or where the
+//      problem is condensed per scenario, a Mehrotra predictor-corrector interior point; every Newton system
+//      K = H + A'DA is factorised K = L D L' with row k of K held in the registers of lane k and the pivot column
+//      broadcast through v_readlane,
 //   5. rolls the prediction out, advances the plant with RK4 and does the lap bookkeeping,
 // and repeats for `nsteps` steps inside one launch (scenarios are independent, so no grid-wide dependency).
 //
@@ -25,6 +27,7 @@
 #include "mpc_kernels.h"
 #include "mpc_wave.hpp"
 #include "mpc_ipm.hpp"
+#include "mpc_aset.hpp"
 
 // Linear algebra below may contract a*b+c; the plant and planner code in mpc_device.hpp is compiled without
 // contraction (command line) so that it rounds like the numpy expressions it restates.
@@ -117,8 +120,63 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W]
-template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W; }
+// A solve of the fixed-model path whose unconstrained minimiser Uu violates a bound: the active-set method where the table
+// T is at hand, the interior point for what it hands on.  One call site in the per-step loop (a function of its own:
+// what the step loop keeps in registers is saved around it only on the steps that get here).
+struct ConstrainedResult {
+    double U, mu, res;
+    int iters, status;           // interior-point iterations and status
+    int work;                    // both methods' iterations in units of a quarter interior-point iteration (launch ordering)
+    bool warm_valid;             // the scenario's record holds this solve's result
+};
+
+template <int N, int TAG>
+static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_constrained(IpmParams prm, int lane, const double *Hm, const double *T,
+                                                                   double Uu, double vdu, double up_d, double lo_d, double *lds,
+                                                                   int *as_o)
+{
+    ConstrainedResult out = {0.0, 0.0, 0.0, 0, 0, 0, false};
+    // Back-off: a scenario whose active-set solves keep being handed on (large sets that jump from step to step, e.g. the
+    // output-feedback loop on a noisy estimate) tries the method again only after 1, 3, 7, 15 steps of interior point alone.
+    // The two counters travel in the scenario's record behind its validity flag.
+    gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
+    const int wait = bo ? __builtin_amdgcn_readfirstlane((int)bo[0]) : 0;       // wave-uniform
+    if (T && wait > 0) {
+        if (lane == 0) bo[0] = (double)(wait - 1);
+    } else if (T) {
+        const AsetResult r = active_set_solve<N, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
+                                                      prm.warm_mode != 0, lds);
+        out.work = r.iters;
+        // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
+        // registers of the step loop they would crowd the unconstrained steps
+        if (as_o && lane == 0) {
+            as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3] += 1;
+            as_o[1] += r.iters;
+        }
+        if (bo && lane == 0) {
+            const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo[1] + 1, 4);
+            bo[1] = (double)streak;
+            bo[0] = (double)((1 << streak) - 1);
+        }
+        if (r.why == ASET_SOLVED) {
+            out.U = r.U; out.warm_valid = prm.warm != nullptr;
+            return out;
+        }
+    }
+    const bool valid = lane < N;
+    double hu = 0.0;                       // g = -H U_unc
+#pragma unroll 10
+    for (int j = 0; j < N; j++) hu = fma(valid ? Hm[j * N + lane] : 0.0, bcast(Uu, j), hu);
+    const IpmResult r = interior_point<N, TAG>(prm, lane, Hm, -hu, up_d, lo_d, (ldouble *)lds);
+    out.U = r.U; out.mu = r.mu; out.res = r.res; out.iters = r.iters; out.status = r.status; out.warm_valid = r.warm_valid;
+    out.work += 4 * r.iters;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W], parked plant state and coefficients
+constexpr int PARK_W = 20;
+template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W; }
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
 constexpr int FIXED_WPB = 4;
 
@@ -145,6 +203,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
     double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
+    double *s_park = wbase + 4 * (N + 1) + N * STAGE_W;   // plant state [10], plant coefficients [7], planner memory and speed while a step's solve runs
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
@@ -210,12 +269,21 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     }
     // constant over the launch: the plant's speed-dependent coefficients (x[4] has zero derivative) and the progress
     // increments of the waypoints (sequentially accumulated like np.cumsum)
-    const PlantCoef pc = plant_coef(mp, plant[4]);
+    // The plant's state and coefficients are needed at the two ends of a step only (reference planning, RK4).  In between
+    // they wait in LDS: held in registers across the solve they push the per-step path into scratch spills.
+    {
+        const PlantCoef pc = plant_coef(mp, plant[4]);
+        if (lane == 0) {
+            s_park[10] = pc.vx; s_park[11] = pc.c11; s_park[12] = pc.c12a; s_park[13] = pc.b1; s_park[14] = pc.c21;
+            s_park[15] = pc.c22; s_park[16] = pc.b2;
+        }
+    }
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
-    int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0;
+    int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0, work_tot = 0;
+    if (lane == 0 && a.as_out && !a.accumulate) { int *o = a.as_out + 4 * (size_t)s; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
     double mu = 0.0, res = 0.0, u0 = 0.0;
 
 #pragma unroll 1
@@ -266,6 +334,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 }
             }
         }
+        if (lane == 0) {                   // (in every mode: a value that may stay in its register on one path stays live on all)
+#pragma unroll
+            for (int i = 0; i < 10; i++) s_park[i] = plant[i];
+            s_park[17] = prevp; s_park[18] = tvel;
+        }
         wave_sync();
 
         // ------------------------------------------------------------ 2. per-stage model (lane k -> stage k)
@@ -281,6 +354,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         steer_bounds(xh5, dmax, umax, dt, lane, up_d, lo_d, relaxed);
         double g = 0.0, U = 0.0;
         int iters = 0, status = 0, constrained = 0;
+        bool need_ipm = false, solved_warm = false;
         const double *Hm;
 
         bool fast = !GENERAL || a.sh_H != nullptr;
@@ -312,13 +386,18 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             const double vd = dt * incl_prefix(Uu, lane);
             bool ok = fabs(Uu) <= umax;
             if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
-            if (__all(ok)) U = Uu;
+            // (the expectation is for the register allocator: what it has to move out of the way of the call below belongs
+            // on that branch, not on the path every step takes)
+            if (__builtin_expect(__all(ok), 1)) U = Uu;
             else {
                 constrained = 1;
-                double hu = 0.0;                       // g = -H U_unc
-#pragma unroll 10
-                for (int j = 0; j < N; j++) hu = fma(valid ? Hm[j * N + lane] : 0.0, bcast(Uu, j), hu);
-                g = -hu;
+                // (s_ref is dead once U_unc is formed: the solvers borrow it)
+                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
+                const ConstrainedResult r = solve_constrained<N, GENERAL ? 1 : 2>(prm, lane, Hm, a.sh_T, Uu, vd, up_d, lo_d, s_ref,
+                                                                                  a.as_out ? a.as_out + 4 * (size_t)s : nullptr);
+                U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
+                solved_warm = (warm_rec != nullptr) && r.warm_valid;
+                work_tot += r.work;
             }
         } else if (!GENERAL) {
             Hm = a.sh_H;
@@ -350,16 +429,17 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             bool ok = fabs(Uu) <= umax;
             if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
             if (__all(ok)) U = Uu;
-            else constrained = 1;
+            else { constrained = 1; need_ipm = true; }
         }
-        if (constrained) {
+        if (need_ipm) {
             // closed loops start the interior point from the previous step's solve when that step needed one too
             const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
             const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)(GENERAL ? s_wv : s_ref));   // both areas are dead by now
             U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
+            work_tot += 4 * r.iters;
             warm_ok = (warm_rec != nullptr) && r.warm_valid;
         } else
-            warm_ok = false;
+            warm_ok = solved_warm;                 // the fixed-model solve left its result in the record, or no solve was needed
         if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible
         status = max(status, lap_flag);
 
@@ -410,7 +490,12 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 if (valid) a.lin_u[(size_t)s * N + lane] = U;
             }
         }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 10; i++) plant[i] = s_park[i];
+        prevp = s_park[17]; tvel = s_park[18];
         if (a.mode != MODE_SOLVE) {
+            const PlantCoef pc = {s_park[10], s_park[11], s_park[12], s_park[13], s_park[14], s_park[15], s_park[16]};
             const double oldx = plant[0];
             plant_rk4_c<10>(plant, u0, dt, pc);                             // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
@@ -452,7 +537,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     if (lane == 0) {
         if (warm_rec) warm_rec[5 * WAVE] = warm_ok ? 1.0 : 0.0;
         if (a.u0_out) a.u0_out[s] = u0;
-        if (a.work_out) a.work_out[s] = iters_tot;
+        if (a.work_out) a.work_out[s] = (work_tot + 3) >> 2;     // in interior-point iterations
         const int st_all = a.accumulate ? max(a.status_own[s], status_max) : status_max;
         const int it_all = a.accumulate ? a.iters_own[s] + iters_tot : iters_tot;
         a.status_own[s] = st_all; a.iters_own[s] = it_all;
@@ -472,7 +557,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
 // Fixed-model cache: condense once for "every stage at speed vx", factor H and apply inv(H) to each way the
 // gradient depends on the step's data.  One wavefront; a set-up cost of about 3N+5 triangular solve pairs.
 template <int N>
-__global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, double vx, double *H, double *Kref, double *Kx)
+__global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, double vx, double *H, double *Kref, double *Kx,
+                                                         double *T)
 {
     const int lane = threadIdx.x;
     const bool valid = lane < N;
@@ -515,19 +601,38 @@ __global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, doubl
         const double x = nt.solve(rhs, lane);
         if (valid) Kref[(size_t)ck * N + lane] = x;
     }
+    // table of the active-set solve (mpc_aset.hpp): G = inv(H), G P' and P G P' with P = dt * (prefix-sum rows), as one
+    // symmetric 2N x 2N matrix [[G, G P'], [P G, P G P']]; column c of G is one solve with a unit vector
+    if (T) {
+        constexpr int LD = 2 * N;
+        double run = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < N; c++) {
+            const double x = nt.solve(lane == c ? 1.0 : 0.0, lane);      // lane i: G[i][c]
+            run += valid ? x : 0.0;
+            const double gp = dt * run;                                    // lane i: (G P')[i][c]
+            const double pgp = dt * incl_prefix(valid ? gp : 0.0, lane);   // lane k: (P G P')[k][c]
+            if (valid) {
+                T[lane * LD + c] = x;
+                T[lane * LD + N + c] = gp;
+                T[(N + c) * LD + lane] = gp;
+                T[(N + lane) * LD + N + c] = pgp;
+            }
+        }
+    }
 }
 
 template <int N>
-static hipError_t launch_fixed_n(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st)
+static hipError_t launch_fixed_n(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_condense_fixed<N>, dim3(1), dim3(WAVE), 0, st, cfg, vx, H, Kref, Kx);
+    hipLaunchKernelGGL(k_condense_fixed<N>, dim3(1), dim3(WAVE), 0, st, cfg, vx, H, Kref, Kx, T);
     return hipGetLastError();
 }
 
-hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, hipStream_t st)
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st)
 {
     switch (cfg.N) {
-#define MPC_CASE(n) case n: return launch_fixed_n<n>(cfg, vx, H, Kref, Kx, st);
+#define MPC_CASE(n) case n: return launch_fixed_n<n>(cfg, vx, H, Kref, Kx, T, st);
         MPC_HORIZONS(MPC_CASE)
 #undef MPC_CASE
     default: return hipErrorInvalidValue;

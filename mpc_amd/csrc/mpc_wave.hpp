@@ -37,7 +37,10 @@ __device__ __forceinline__ void axpy_from_lds(double (&row)[N], const double *sr
 template <int N>
 __device__ __forceinline__ double dot_column(const double *K, const double *r, int col)
 {
-    constexpr int CH = (N % 10 == 0) ? 10 : 8, G = N / CH;
+#ifndef MPC_DOT_CH
+#define MPC_DOT_CH 10
+#endif
+    constexpr int CH = (N % 10 == 0) ? MPC_DOT_CH : 8, G = N / CH;
     static_assert(N % CH == 0, "horizon must be a multiple of 10 or of 8");
     double kv[2][CH], rv[2][CH];
 #pragma unroll
@@ -53,7 +56,7 @@ __device__ __forceinline__ double dot_column(const double *K, const double *r, i
 #pragma unroll
         for (int u = 0; u < CH; u += 2) {
             acc0 = fma(kv[g & 1][u], rv[g & 1][u], acc0);
-            acc1 = fma(kv[g & 1][u + 1], rv[g & 1][u + 1], acc1);
+            if (u + 1 < CH) acc1 = fma(kv[g & 1][u + 1], rv[g & 1][u + 1], acc1);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,0 +1,117 @@
+"""The active-set solve of the fixed-model path (mpc_amd/csrc/mpc_aset.hpp) against the 80-bit checker and against the
+interior point.  Both GPU methods and the checker's stage-wise Riccati interior point are three different algorithms for
+the unique minimiser of the problem LMPC2.py:196-260 poses; the bar is the per-step input bar of the other parity tests,
+1e-5 relative with a floor of 1e-3 of the rate bound (parity unpinned, as for every QP solve: the reference's own solver is
+not available)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(u_ref, umax):
+    return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
+
+
+def _starts(B, seed):
+    rng = np.random.default_rng(seed)
+    psi = rng.uniform(-0.1, 0.1, B)
+    return np.stack([np.full(B, 15.0), rng.uniform(-0.3, 0.3, B), np.cos(psi), np.sin(psi), np.full(B, 8.0),
+                     rng.uniform(-0.2, 0.2, B), rng.uniform(-0.2, 0.2, B), rng.uniform(-0.05, 0.05, B)], axis=1)
+
+
+@pytest.mark.parametrize("N,Tf,nsteps", [(50, 0.5, 90), (10, 0.1, 40), (20, 0.2, 40), (30, 0.3, 40), (40, 0.4, 40), (64, 0.64, 60)])
+def test_every_closed_loop_step_matches_checker(orc80, N, Tf, nsteps):
+    """Every step of every sampled scenario is solved again by the checker from the state the GPU run recorded (so the
+    comparison is per step, with no feedback of differences), through the start transient (sets of up to ~2N - 1 bounds,
+    all three size classes, hand-overs to the interior point) and the steps behind it (a few bounds)."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    B = 96
+    st = _starts(B, 11)
+    cfg = O.make_cfg("L", N, Tf)
+    umax = cfg[10]
+    sim = SkidpadBatch(N, Tf, st, model="L")
+    xs, us = sim.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    xs = xs.cpu().numpy(); us = us.cpu().numpy()
+    assert (sim.status.cpu().numpy() == 0).all()
+    stats = sim.ocp.stats()
+    assert stats["n_active_set_solves"] >= 0.5 * stats["n_constrained"] > 0          # the method under test did the work
+    for b in range(0, B, 4):
+        lap = 0
+        for t in range(nsteps):
+            x = st[b] if t == 0 else xs[t - 1, b]
+            _, _, _, _, u_ref, _ = orc80.skidpad_step(cfg, x.copy(), lap, 0.0, 8.0)
+            assert abs(us[t, b] - u_ref) <= _tol(u_ref, umax), (N, b, t, us[t, b], u_ref)
+            if xs[t, b, 0] > 16.75 and x[0] <= 16.75:                                  # skidpad_simulator.py:91-93
+                lap += 1
+
+
+def test_active_set_and_interior_point_agree_on_the_skidpad():
+    """The same 512 closed loops with both methods: inputs within 10x the bar (differences feed back), states 1e-7."""
+    import torch
+    from mpc_amd.batched import SkidpadBatch
+    st = _starts(512, 5)
+    runs = {}
+    for method in ("auto", "interior_point"):
+        sim = SkidpadBatch(50, 0.5, st, model="L", qp_method=method)
+        xs, us = sim.run(120, record=True)
+        torch.cuda.synchronize()
+        assert (sim.status.cpu().numpy() == 0).all()
+        runs[method] = (xs.cpu().numpy(), us.cpu().numpy(), sim.ocp.stats())
+    assert runs["interior_point"][2]["n_active_set_solves"] == 0
+    assert runs["auto"][2]["n_active_set_solves"] > 0
+    assert runs["auto"][2]["sum_iterations"] < 0.5 * runs["interior_point"][2]["sum_iterations"]
+    ua, ub = runs["auto"][1], runs["interior_point"][1]
+    assert (np.abs(ua - ub) <= 10 * _tol(ub, 0.9)).all(), np.abs(ua - ub).max()
+    assert np.abs(runs["auto"][0] - runs["interior_point"][0]).max() <= 1e-7
+
+
+def test_output_feedback_loop_with_noise_in_both_methods():
+    """BASELINE config 4 (simulator.py:206-281): the noisy output-feedback loop; same noise tensor, both methods.  On the
+    way to the step every input of these problems is fixed by a bound (full rate until the steering angle saturates, then
+    the angle bound to the end of the horizon: as many active bounds as inputs), which the multiplier system of the
+    active-set method does not resolve in double precision; its attempts are handed to the interior point and backed
+    off, so the two runs must agree and the attempts must stay a small share of the solves."""
+    import torch
+    from mpc_amd.batched import StepOFLBatch
+    B, n = 256, 80
+    rng = np.random.default_rng(2)
+    x = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, -10.0, 0.0]), (B, 1))
+    x[:, 1] = rng.uniform(-0.2, 0.2, B)
+    sigma = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])                           # continuous_dynamics.py:68-72
+    noise = rng.standard_normal((n, B, 7)) * sigma * 0.2
+    out = {}
+    for method in ("auto", "interior_point"):
+        sim = StepOFLBatch(50, 0.5, x, qp_method=method)
+        xs, us, es = sim.run(n, record=True, meas_noise=noise)
+        torch.cuda.synchronize()
+        out[method] = (xs.cpu().numpy(), us.cpu().numpy(), sim.status.cpu().numpy(), sim.ocp.stats())
+    assert (out["auto"][2] == out["interior_point"][2]).all() and np.isin(out["auto"][2], (0, 4)).all()
+    sa = out["auto"][3]
+    attempts = sa["n_active_set_solves"] + sa["n_active_set_too_large"] + sa["n_active_set_unsettled"]
+    assert 0 < attempts <= 0.25 * sa["n_constrained"]
+    ua, ub = out["auto"][1], out["interior_point"][1]
+    assert (np.abs(ua - ub) <= 10 * _tol(ub, 0.9)).all(), np.abs(ua - ub).max()
+    assert np.abs(out["auto"][0] - out["interior_point"][0]).max() <= 1e-7
+
+
+def test_fused_launch_equals_per_step_launches_bit_for_bit():
+    """The set a solve starts from travels in the scenario's record in HBM between launches exactly as inside one."""
+    import torch
+    from mpc_amd.batched import SkidpadBatch
+    st = _starts(300, 9)
+    a = SkidpadBatch(50, 0.5, st, model="L")
+    b = SkidpadBatch(50, 0.5, st, model="L")
+    xa, ua = a.run(70, record=True)
+    ub = []
+    for _ in range(70):
+        _, u = b.run(1, record=True)
+        ub.append(u)
+    torch.cuda.synchronize()
+    assert torch.equal(ua, torch.cat(ub, 0))
+    assert torch.equal(a.state, b.state)
+    sa, sb = a.ocp.stats(), b.ocp.stats()
+    assert sa["n_active_set_solves"] > 0
