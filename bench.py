@@ -50,7 +50,7 @@ def ipm_flops(N: int) -> float:
     return N ** 3 / 3 + 9 * N * N + 100 * N
 
 
-def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0, ncomp: int = 3) -> float:
+def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0, ncomp: int = 3, extra: float = 0.0) -> float:
     """FP64 flops one scenario-step needs with the method that is run (symmetry and zero weights exploited).
     c2/c4 (speed constant, problem condensed once per launch and shared): planner 60(N+1); unconstrained minimiser as
     an affine map of the step's data, `ncomp` weighted reference components (2 with the yaml's weights: the x weight is
@@ -62,7 +62,9 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
     the barrier terms 400, affine forward sweep 120, corrector backward sweep 150, corrector forward sweep 130).
     c5, per SQP iteration: RK4 roll-out 160N; RK4 derivative 700N; prediction columns 52N^2/2; Hessian, 5 weighted
     outputs, 5N^3/3; gradient and H*U 4N^2; LDL' N^3/3 + 2N^2.
-    Every interior-point iteration of c2/c4/c5 adds ipm_flops(N)."""
+    Every interior-point iteration of c2/c4/c5 adds ipm_flops(N); the active-set solves of c2/c4 add the count the kernel
+    keeps for them (`extra`, per scenario-step: LDL' of the m x m multiplier system m^3/3, two solves 2m^2, the update of
+    the inputs 2mN, scans ~20N per iteration; 4N^2 + 2m^2 + 2mN per certificate pass)."""
     plan = 60 * (N + 1) + 400
     if workload in ("c2", "c4"):
         fixed = plan + 2 * (ncomp * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)
@@ -70,7 +72,7 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
         return plan + N * (130 + 300 + 880 * mean_iters)
     else:
         fixed = plan + mean_sqp * (860 * N + 26 * N * N + 5 * N ** 3 / 3 + 4 * N * N + N ** 3 / 3 + 2 * N * N)
-    return fixed + ipm_flops(N) * mean_iters
+    return fixed + ipm_flops(N) * mean_iters + extra
 
 
 def weighted_reference_components(ocp) -> int:
@@ -224,7 +226,8 @@ def build_workload(name: str, B: int, rank: int, dev, steps_total: int):
     raise ValueError(name)
 
 
-SUM_KEYS = ("scenario_steps", "ipm_iterations", "constrained_solves", "status_nonzero", "sqp_iterations", "sum_abs_u0")
+SUM_KEYS = ("scenario_steps", "ipm_iterations", "constrained_solves", "status_nonzero", "sqp_iterations", "sum_abs_u0",
+            "active_set_solves", "active_set_iterations", "active_set_handed_on", "active_set_flops")
 MAX_KEYS = ("elapsed_s", "max_abs_u0", "max_complementarity", "max_residual")
 
 
@@ -264,7 +267,9 @@ def dry_run(args, rank: int, world: int) -> None:
     B = args.batch or WORKLOADS[args.workload]["B"]
     lo, hi = shard_bounds(B * world, rank, world)
     sums = {"scenario_steps": (hi - lo) * args.steps, "ipm_iterations": 2.0 * (hi - lo) * args.steps,
-            "constrained_solves": 0.5 * (hi - lo) * args.steps, "status_nonzero": 0, "sqp_iterations": 0, "sum_abs_u0": 0.1 * (hi - lo)}
+            "constrained_solves": 0.5 * (hi - lo) * args.steps, "status_nonzero": 0, "sqp_iterations": 0, "sum_abs_u0": 0.1 * (hi - lo),
+            "active_set_solves": 0.4 * (hi - lo) * args.steps, "active_set_iterations": 1.0 * (hi - lo) * args.steps,
+            "active_set_handed_on": 0.1 * (hi - lo) * args.steps, "active_set_flops": 1e4 * (hi - lo) * args.steps}
     maxima = {"elapsed_s": 1.0 + rank, "max_abs_u0": 0.1 * (rank + 1), "max_complementarity": 1e-16, "max_residual": 1e-13}
     sums, maxima = reduce_statistics(sums, maxima)
     if rank == 0:
@@ -373,7 +378,11 @@ def main() -> None:
     n_constr = float((iters_hist > 0).sum().item()) if args.per_step_launch else float(st16["n_constrained"])
     sums = {"scenario_steps": B * args.steps, "ipm_iterations": float(iters_hist.sum().item()), "constrained_solves": n_constr,
             "status_nonzero": float((status_timed != 0).sum().item()), "sqp_iterations": float(st16["sum_sqp_iterations"]),
-            "sum_abs_u0": float(st16["sum_abs_u0"])}
+            "sum_abs_u0": float(st16["sum_abs_u0"]),
+            # the active-set counters describe the last launch: the timed region in the fused mode, its last step otherwise
+            "active_set_solves": float(st16["n_active_set_solves"]), "active_set_iterations": float(st16["sum_active_set_iterations"]),
+            "active_set_handed_on": float(st16["n_active_set_too_large"] + st16["n_active_set_unsettled"]),
+            "active_set_flops": float(st16["sum_active_set_flops"])}
     maxima = {"elapsed_s": elapsed, "max_abs_u0": float(st16["max_abs_u0"]), "max_complementarity": float(st16["max_complementarity"]),
               "max_residual": float(st16["max_residual"])}
     sums, maxima = reduce_statistics(sums, maxima, dev)       # RCCL: the only collective of the path
@@ -406,7 +415,8 @@ def main() -> None:
         mean_iters = sums["ipm_iterations"] / total
         mean_sqp = sums["sqp_iterations"] / total
         ncomp = weighted_reference_components(sim.ocp) if args.workload in ("c2", "c4") else 3
-        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp, ncomp)
+        as_scale = 1.0 if not args.per_step_launch else float(args.steps)      # per-step launches: the last step stands for all
+        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp, ncomp, extra=as_scale * sums["active_set_flops"] / total)
         launch_s = float(kernel_ms.mean()) * 1e-3
         ach_tflops = flops * B * steps_per_launch / launch_s / 1e12
         out = {
@@ -429,6 +439,11 @@ def main() -> None:
             "solver": {"mean_ipm_iterations_per_scenario_step": mean_iters,
                        "constrained_qp_per_scenario_step": sums["constrained_solves"] / total,
                        "mean_sqp_iterations_per_scenario_step": mean_sqp if args.workload == "c5" else None,
+                       "active_set": None if args.workload not in ("c2", "c4") else {
+                           "solves_per_scenario_step": as_scale * sums["active_set_solves"] / total,
+                           "iterations_per_solve": sums["active_set_iterations"] / max(1.0, sums["active_set_solves"] + sums["active_set_handed_on"]),
+                           "handed_to_interior_point_per_scenario_step": as_scale * sums["active_set_handed_on"] / total,
+                           "flops_per_scenario_step": as_scale * sums["active_set_flops"] / total},
                        "status_nonzero_last_launch": int(sums["status_nonzero"]),
                        "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(torch.bincount(status_timed.long()).tolist()) if v},
                        "max_abs_u0": maxima["max_abs_u0"], "max_complementarity": maxima["max_complementarity"],

@@ -277,7 +277,8 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream);
  *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual, [8] sum of SQP iterations (MPC_KIND_NL),
  *   [9] constrained solves finished by the active-set method, [10] sum of its iterations, [11] solves it handed to the
  *   interior point because the active set outgrew its capacity or was rank-deficient, [12] because its iteration did not
- *   settle or its result did not certify; rest reserved.
+ *   settle or its result did not certify, [13] floating-point operations of the active-set solves (the method's own
+ *   count); rest reserved.
  *   [1] counts interior-point iterations only. */
 int mpc_get_stats(mpc_handle *h, void *stream, double *host16);
 

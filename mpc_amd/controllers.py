@@ -327,8 +327,8 @@ class _CondensedMpc:
         _lib.check(rc, self.solver.h, "mpc_get_stats")
         keys = ["scenarios", "sum_iterations", "n_status_nonzero", "n_constrained", "sum_abs_u0", "max_abs_u0",
                 "max_complementarity", "max_residual", "sum_sqp_iterations", "n_active_set_solves",
-                "sum_active_set_iterations", "n_active_set_too_large", "n_active_set_unsettled"]
-        return dict(zip(keys, out[:13]))
+                "sum_active_set_iterations", "n_active_set_too_large", "n_active_set_unsettled", "sum_active_set_flops"]
+        return dict(zip(keys, out[:14]))
 
 
 class LOcp(_CondensedMpc):

@@ -28,7 +28,7 @@ struct mpc_handle {
     double *stats16 = nullptr;   // device result of the statistics reduction
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double *sh_T = nullptr;      // table of the active-set solve (part of the cache; NULL with qp_method = interior point)
-    int *as2 = nullptr;          // B * 4: active-set counters of the last call (SolveArgs::as_out)
+    int *as2 = nullptr;          // B * 6: active-set counters of the last call (SolveArgs::as_out)
     double sh_vx = 0.0;
     int sh_mask = 0;
     bool sh_on = false, sh_exclusive = false;
@@ -159,8 +159,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&h->as2, B * 4 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->as2, 0, B * 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->as2, B * 6 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->as2, 0, B * 6 * sizeof(int));
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "mpc_create: workspace allocation");
         mpc_destroy(h);

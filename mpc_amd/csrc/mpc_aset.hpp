@@ -35,16 +35,20 @@ constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a
 // sizes of the certificate's corrections relative to the input bound: a first correction below EARLY is taken as final
 // (what is left after it is smaller by the accuracy of the cached inverse), a later one has to come out below TOL
 #ifndef ASET_DU_EARLY
-#define ASET_DU_EARLY 0.0
+#define ASET_DU_EARLY 1e-6
 #endif
 constexpr double ASET_DU_TOL = 1e-10;
 // A pivot below this fraction of the row's own diagonal entry: the bound's row depends on the rows before it
 constexpr double ASET_PIV_MIN = 1e-9;
 
-// The multiplier system is solved in one of three sizes (straight-line code each, rows beyond the set are unit rows)
-template <int N> constexpr int aset_class(int i) { return i == 0 ? 16 : i == 1 ? (2 * N < 32 ? 2 * N : 32) : (2 * N < 64 ? 2 * N : 64); }
-// LDS the solve borrows from the wave's area: the list of active bounds (ints) and one list of doubles
-template <int N> constexpr int aset_lds_doubles() { return aset_class<N>(2) / 2 + aset_class<N>(2); }
+// The multiplier system is solved in one of four sizes (straight-line code each, rows beyond the set are unit rows)
+template <int N> constexpr int aset_class(int i) { return 2 * N < 16 * (i + 1) ? 2 * N : 16 * (i + 1); }
+constexpr int ASET_CLASSES = 4;
+// LDS the solve borrows from the wave's area (4 (N + 1) doubles: references and speeds, dead once the unconstrained
+// minimiser is formed): the list of active bounds (ints), one list of doubles and, where it fits, the 64-double slot the
+// larger classes broadcast their pivot columns through
+template <int N> constexpr int aset_list_doubles() { return aset_class<N>(ASET_CLASSES - 1) / 2 + aset_class<N>(ASET_CLASSES - 1); }
+template <int N> constexpr bool aset_lds_broadcast() { return aset_list_doubles<N>() + 64 <= 4 * (N + 1); }
 
 // LDL' of an MM x MM matrix, row r in the registers of lane r (statically indexed), the pivot column broadcast through
 // v_readlane.  A step whose pivot shows that the row depends on the rows before it is skipped: the multiplier of that
@@ -54,39 +58,66 @@ struct SmallLdl {
     double row[MM];
     double dinv;
 
-    template <int K>
-    __device__ __forceinline__ void eliminate(int lane, double diag)
+    // Entry j of the pivot column reaches every lane through v_readlane (two VALU issues per value) or, with USE_LDS, is
+    // read back from a 64-double LDS slot `bc` that every lane has written its entry to: all but the first few columns
+    // of a step (a multiple of the group size goes through LDS), the reads issued a group ahead of their multiply-adds.
+    template <int K, bool USE_LDS>
+    __device__ __forceinline__ void eliminate(int lane, int lane_in, double diag, aset_ldouble *bc)
     {
+        constexpr int LG = 8;
+        constexpr int M = MM - 1 - K;
+        constexpr int NL = (USE_LDS && M >= 2 * LG) ? (M / LG) * LG : 0;
+        constexpr int JL = MM - NL;
         const double c = row[K];
+        if (NL) bc[lane_in] = c;
         const double piv = bcast(c, K);
         const double inv = piv > ASET_PIV_MIN * bcast(diag, K) ? fast_rcp(piv) : 0.0;
         const bool below = lane > K;
         const double l = below ? c * inv : 0.0;
         if (lane == K) dinv = inv;
+        double t[2][LG];
+        if (NL) {
 #pragma unroll
-        for (int j0 = K + 1; j0 < MM; j0 += 4) {
+            for (int u = 0; u < LG; u++) t[0][u] = bc[JL + u];
+        }
+#pragma unroll
+        for (int j0 = K + 1; j0 < JL; j0 += 4) {
             double cj[4];
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                if (j0 + g < MM) cj[g] = bcast_pinned(c, j0 + g);
+                if (j0 + g < JL) cj[g] = bcast_pinned(c, j0 + g);
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                if (j0 + g < MM) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
+                if (j0 + g < JL) row[j0 + g] = fma(-l, cj[g], row[j0 + g]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g0 = 0; g0 < NL; g0 += LG) {
+            const int cur = (g0 / LG) & 1;
+            if (g0 + LG < NL) {
+#pragma unroll
+                for (int u = 0; u < LG; u++) t[cur ^ 1][u] = bc[JL + g0 + LG + u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LG; u++) row[JL + g0 + u] = fma(-l, t[cur][u], row[JL + g0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (below) row[K] = l;
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    template <int... Ks>
-    __device__ __forceinline__ void eliminate_all(int lane, double diag, std::integer_sequence<int, Ks...>)
+    template <bool USE_LDS, int... Ks>
+    __device__ __forceinline__ void eliminate_all(int lane, int lane_in, double diag, aset_ldouble *bc, std::integer_sequence<int, Ks...>)
     {
-        (eliminate<Ks>(lane, diag), ...);
+        (eliminate<Ks, USE_LDS>(lane, lane_in, diag, bc), ...);
     }
 
-    __device__ __forceinline__ void factor(int lane_in, double diag)
+    template <bool USE_LDS>
+    __device__ __forceinline__ void factor(int lane_in, double diag, aset_ldouble *bc)
     {
         dinv = 1.0;
-        eliminate_all(opaque_int(lane_in), diag, std::make_integer_sequence<int, MM>{});
+        eliminate_all<USE_LDS>(opaque_int(lane_in), lane_in, diag, bc, std::make_integer_sequence<int, MM>{});
     }
 
     __device__ __forceinline__ double solve(double b, int lane_in) const
@@ -107,12 +138,40 @@ struct SmallLdl {
     }
 };
 
+// acc + sign * sum_{s < m} w_s * T[bound of lane s][col]: the columns of inv(H) [I P'] of the set's bounds against their
+// multipliers (w in lanes 0..m-1, the bounds' rows in my_cid).  CH rows are requested before the first is used: one
+// memory round trip per CH bounds instead of one per bound.
+template <unsigned LD, int CH>
+__device__ __forceinline__ double aset_combine(const aset_gdouble *Tg, int my_cid, double w, int m, unsigned col, double acc, double sign)
+{
+    double acc1 = 0.0;
+#pragma unroll 1
+    for (int s0 = 0; s0 < m; s0 += CH) {
+        double t[CH], n[CH];
+#pragma unroll
+        for (int g = 0; g < CH; g++) {
+            const int sl = min(s0 + g, m - 1);
+            const int cs = __builtin_amdgcn_readlane(my_cid, sl);
+            t[g] = (Tg + (unsigned)cs * LD)[col];
+            n[g] = (s0 + g < m) ? bcast(w, sl) : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < CH; g += 2) {
+            acc = fma(sign * n[g], t[g], acc);
+            acc1 = fma(sign * n[g + 1], t[g + 1], acc1);
+        }
+    }
+    return acc + acc1;
+}
+
 enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 };
 
 struct AsetResult {
     double U;          // the minimiser (this lane's input), valid when why == ASET_SOLVED
     int au, ad;        // this lane's input / steering bound in the set: +1 upper, -1 lower, 0 none
     int iters;         // active-set iterations spent so far
+    int flops;         // floating-point operations spent so far (the method's own count: LDL' m^3/3, two solves 2m^2,
+                       // the update of the inputs 2mN, scans ~20N per iteration; 4N^2 + 2m^2 + 2mN per certificate pass)
     int why;           // ASET_SOLVED, or handed on: GROW the set outgrew this size class, UNSETTLED the iteration did not
                        // settle within ASET_MAX_ITER, UNCERTIFIED the corrections of the certificate stayed too large
 };
@@ -121,26 +180,28 @@ struct AsetResult {
 // minimiser (0 beyond the horizon), vdu = dt * prefix sum of Uu; up_d / lo_d: this lane's steering bounds
 // (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
 // ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
-// written with the result when the solve succeeds (or NULL); lds: aset_lds_doubles<N>() doubles of this wave.
+// written with the result when the solve succeeds (or NULL); lds: the wave's 4 (N + 1) doubles of references and speeds.
 // Not inlined, like the interior point: the registers of a size class (the row of its multiplier system) stay out of the
 // per-step path's allocation, and the smallest class, which serves most solves, saves and restores few of them.  TAG
 // gives every calling kernel its own copies with that kernel's register budget.
 template <int N, int MM>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
-                                                double *rec, int au, int ad, int it0, double *lds)
+                                                double *rec, int au, int ad, int it0, int fl0, double *lds)
 {
     constexpr unsigned LD = 2 * N;                       // row length of T
     const bool valid = lane < N, validd = lane < N - 1;
     const unsigned lc = valid ? lane : 0;
     aset_lint *cid_l = (aset_lint *)lds;
-    aset_ldouble *val_l = (aset_ldouble *)(lds + aset_class<N>(2) / 2);
+    aset_ldouble *val_l = (aset_ldouble *)(lds + aset_class<N>(ASET_CLASSES - 1) / 2);
+    aset_ldouble *bc = (aset_ldouble *)(lds + aset_list_doubles<N>());
+    constexpr bool USE_LDS = MM >= 32 && aset_lds_broadcast<N>();
     const aset_gdouble *Tg = (const aset_gdouble *)T;
     const aset_gdouble *Hg = (const aset_gdouble *)Hm;
     const double tol_u = 1e-12 * umax, tol_d = 1e-12 * dmax;
 
     SmallLdl<MM> ldl;
-    AsetResult out = {0.0, au, ad, it0, ASET_UNSETTLED};
+    AsetResult out = {0.0, au, ad, it0, fl0, ASET_UNSETTLED};
     double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0;
     int my_cid = 0, m = 0, rank_u = 0, rank_d = 0;
     bool converged = false;
@@ -151,6 +212,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         m = m_u + __popcll(mask_d);
         if (m > MM) { out.au = au; out.ad = ad; out.iters = it; out.why = ASET_GROW; return out; }
         out.iters = it + 1;
+        out.flops += m * m * m / 3 + 2 * m * m + 2 * m * N + 20 * N;
         const unsigned long long below = (1ull << lane) - 1ull;
         rank_u = __popcll(mask_u & below);
         rank_d = m_u + __popcll(mask_d & below);
@@ -172,7 +234,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             const double t = (Tg + cs)[rowoff];
             ldl.row[s] = (act && s < m) ? t : (lane_o == s ? 1.0 : 0.0);
         }
-        ldl.factor(lane, diag0);
+        ldl.template factor<USE_LDS>(lane, diag0, bc);
         nu = ldl.solve(my_d, lane);
         // a bound whose row depends on the rows before it (an input run that already fixes a steering row, ...) was left
         // out of the system: it leaves the set here (not-a-number fails the sign test below) and comes back if violated
@@ -182,17 +244,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         nu_d = ad != 0 ? val_l[rank_d] : 0.0;
         wave_sync();
         // U = Uu - sum_s nu_s * (column of inv(H) [I P'] of bound s)
-        double acc0 = Uu, acc1 = 0.0;
-#pragma unroll 1
-        for (int s = 0; s < m; s += 2) {
-            const int c0 = __builtin_amdgcn_readlane(my_cid, s);
-            const int c1 = __builtin_amdgcn_readlane(my_cid, min(s + 1, m - 1));
-            const double t0 = (Tg + (unsigned)c0 * LD)[lc], t1 = (Tg + (unsigned)c1 * LD)[lc];
-            const double n0 = bcast(nu, s), n1 = (s + 1 < m) ? bcast(nu, min(s + 1, m - 1)) : 0.0;
-            acc0 = fma(-n0, t0, acc0);
-            acc1 = fma(-n1, t1, acc1);
-        }
-        U = valid ? acc0 + acc1 : 0.0;
+        U = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, nu, m, lc, Uu, -1.0) : 0.0;
         const double vd = dt * incl_prefix(U, lane);
         // next set: the one bound whose multiplier has the wrong sign by the most (or whose row was left out) goes, the
         // one bound the new point violates by the most comes in.  (Exchanging every such bound at once is quicker when
@@ -227,20 +279,34 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     bool certified = false;
 #pragma unroll 1
     for (int pass = 0; pass < 3 && !certified; pass++) {
+        out.flops += 4 * N * N + 2 * m * m + 2 * m * N;
         const double dU = valid ? U - Uu : 0.0;
+        // (a column of H, then one of inv(H): every entry requested before the first is used, one round trip each)
         double hu0 = 0.0, hu1 = 0.0;
-#pragma unroll 10
-        for (int j = 0; j < N; j += 2) {
-            hu0 = fma(Hg[j * N + lc], bcast(dU, j), hu0);
-            if (j + 1 < N) hu1 = fma(Hg[(j + 1) * N + lc], bcast(dU, j + 1), hu1);
+        {
+            double hc[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) hc[j] = Hg[j * N + lc];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < N; j += 2) {
+                hu0 = fma(hc[j], bcast(dU, j), hu0);
+                if (j + 1 < N) hu1 = fma(hc[j + 1], bcast(dU, j + 1), hu1);
+            }
         }
         const double frc = nu_u + dt * incl_suffix(validd ? nu_d : 0.0, lane);      // (E' nu)[lane]
         const double r = valid ? hu0 + hu1 + frc : 0.0;
         double z0 = 0.0, z1 = 0.0;
-#pragma unroll 10
-        for (int j = 0; j < N; j += 2) {
-            z0 = fma(Tg[j * LD + lc], bcast(r, j), z0);
-            if (j + 1 < N) z1 = fma(Tg[(j + 1) * LD + lc], bcast(r, j + 1), z1);
+        {
+            double gc[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) gc[j] = Tg[j * LD + lc];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < N; j += 2) {
+                z0 = fma(gc[j], bcast(r, j), z0);
+                if (j + 1 < N) z1 = fma(gc[j + 1], bcast(r, j + 1), z1);
+            }
         }
         const double z = valid ? z0 + z1 : 0.0;
         const double pz = dt * incl_prefix(z, lane);
@@ -257,17 +323,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         if (au != 0) nu_u -= val_l[rank_u];
         if (ad != 0) nu_d -= val_l[rank_d];
         wave_sync();
-        double c0a = -z, c1a = 0.0;
-#pragma unroll 1
-        for (int s = 0; s < m; s += 2) {
-            const int c0 = __builtin_amdgcn_readlane(my_cid, s);
-            const int c1 = __builtin_amdgcn_readlane(my_cid, min(s + 1, m - 1));
-            const double t0 = (Tg + (unsigned)c0 * LD)[lc], t1 = (Tg + (unsigned)c1 * LD)[lc];
-            const double n0 = bcast(dn, s), n1 = (s + 1 < m) ? bcast(dn, min(s + 1, m - 1)) : 0.0;
-            c0a = fma(n0, t0, c0a);
-            c1a = fma(n1, t1, c1a);
-        }
-        const double corr = valid ? c0a + c1a : 0.0;
+        const double corr = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, dn, m, lc, -z, 1.0) : 0.0;
         U += corr;
         const double cmax = wave_max(fabs(corr));
         certified = cmax <= (pass == 0 ? ASET_DU_EARLY : ASET_DU_TOL) * umax;
@@ -296,11 +352,11 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     return out;
 }
 
-// The three size classes as functions of their own, each held to the registers its system needs (the attribute takes a
+// The size classes as functions of their own, each held to the registers its system needs (the attribute takes a
 // literal): what a function uses of the callee-saved registers it saves and restores on every call.
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
-                      double dmax, double dt, double *rec, int au, int ad, int it0, double *lds
-#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, lds
+                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds
+#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds
 template <int N, int MM, int TAG>
 static __device__ __noinline__ AsetResult aset_run_small(MPC_ASET_ARGS)
 {
@@ -316,6 +372,11 @@ static __device__ __noinline__ AsetResult aset_run_large(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }
+template <int N, int MM, int TAG>
+static __device__ __noinline__ AsetResult aset_run_full(MPC_ASET_ARGS)
+{
+    return aset_body<N, MM>(MPC_ASET_PASS);
+}
 #undef MPC_ASET_ARGS
 #undef MPC_ASET_PASS
 
@@ -327,7 +388,7 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
                                                        double *rec, bool rec_valid, double *lds)
 {
-    constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2);
+    constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3);
     const bool valid = lane < N, validd = lane < N - 1;
     int au = 0, ad = 0;
     if (rec_valid) {
@@ -344,17 +405,21 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     if (!valid) au = 0;
     if (!validd) ad = 0;
     wave_sync();                                         // the borrowed LDS area is still being read as something else
-    AsetResult r = {0.0, au, ad, 0, ASET_GROW};
+    AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
     int m = __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0));
     if (!rec_valid && m > ASET_COLD_MAX) return r;       // a large violated set says little about the active one
-    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
     if (C1 > C0 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, lds);
+        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
+    }
+    if (C3 > C2 && r.why == ASET_GROW) {
+        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
     }
     return r;
 }

@@ -507,26 +507,26 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
 __global__ __launch_bounds__(256) void k_stats(int B, const double *stat, const int *iters, const int *status,
                                                const int *sqp, const int *as2, double *out16)
 {
-    __shared__ double sh[13][256];
-    double acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ double sh[14][256];
+    double acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = threadIdx.x; s < B; s += 256) {
         const double *q = stat + 4 * (size_t)s;
         acc[0] += 1.0; acc[1] += iters[s]; acc[2] += (status[s] != 0); acc[3] += q[2]; acc[4] += q[3];
         acc[5] = fmax(acc[5], q[3]);
         if (q[2] != 0.0) { acc[6] = fmax(acc[6], q[0]); acc[7] = fmax(acc[7], q[1]); }
         if (sqp) acc[8] += sqp[s];
-        if (as2) { acc[9] += as2[4 * s]; acc[10] += as2[4 * s + 1]; acc[11] += as2[4 * s + 2]; acc[12] += as2[4 * s + 3]; }
+        if (as2) { acc[9] += as2[6 * s]; acc[10] += as2[6 * s + 1]; acc[11] += as2[6 * s + 2]; acc[12] += as2[6 * s + 3]; acc[13] += 64.0 * as2[6 * s + 4]; }
     }
-    for (int c = 0; c < 13; c++) sh[c][threadIdx.x] = acc[c];
+    for (int c = 0; c < 14; c++) sh[c][threadIdx.x] = acc[c];
     __syncthreads();
     for (int w = 128; w; w >>= 1) {
         if ((int)threadIdx.x < w)
-            for (int c = 0; c < 13; c++)
+            for (int c = 0; c < 14; c++)
                 sh[c][threadIdx.x] = (c < 5 || c >= 8) ? sh[c][threadIdx.x] + sh[c][threadIdx.x + w]
                                              : fmax(sh[c][threadIdx.x], sh[c][threadIdx.x + w]);
         __syncthreads();
     }
-    if (threadIdx.x < 16) out16[threadIdx.x] = threadIdx.x < 13 ? sh[threadIdx.x][0] : 0.0;
+    if (threadIdx.x < 16) out16[threadIdx.x] = threadIdx.x < 14 ? sh[threadIdx.x][0] : 0.0;
 }
 
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,

@@ -66,8 +66,9 @@ struct SolveArgs {
     const double *sh_Kref;   // [3][N][N]: inv(H) * d g / d ref_c(stage k+1), stored [c][k][i]
     const double *sh_Kx;     // [5][N]: -inv(H) * g for unit vy, r, delta, the constant term, unit d_hat
     const double *sh_T;      // [2N][2N]: [I; P] inv(H) [I P'], P = the steering rows (active-set solve; NULL: interior point only)
-    int *as_out;             // [B][4]: active-set solves that ended at the minimiser, active-set iterations, solves handed to the
-                             // interior point because the set was too large or rank-deficient / did not settle or certify (or NULL)
+    int *as_out;             // [B][6]: active-set solves that ended at the minimiser, active-set iterations, solves handed to the
+                             // interior point because the set outgrew the capacity / did not settle or certify, the method's
+                             // flops in units of 64, one spare (or NULL)
     double sh_vx;
     int sh_exclusive;        // caller promises every scenario runs at sh_vx: launch the fixed-model-only kernel
     int sh_mask;             // bit c set: reference component c (x, y, sin psi) carries weight

@@ -152,6 +152,7 @@ static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_con
         if (as_o && lane == 0) {
             as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3] += 1;
             as_o[1] += r.iters;
+            as_o[4] += (r.flops + 32) >> 6;
         }
         if (bo && lane == 0) {
             const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo[1] + 1, 4);
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0, work_tot = 0;
-    if (lane == 0 && a.as_out && !a.accumulate) { int *o = a.as_out + 4 * (size_t)s; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
+    if (lane == 0 && a.as_out && !a.accumulate) { int *o = a.as_out + 6 * (size_t)s; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; }
     double mu = 0.0, res = 0.0, u0 = 0.0;
 
 #pragma unroll 1
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 // (s_ref is dead once U_unc is formed: the solvers borrow it)
                 const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
                 const ConstrainedResult r = solve_constrained<N, GENERAL ? 1 : 2>(prm, lane, Hm, a.sh_T, Uu, vd, up_d, lo_d, s_ref,
-                                                                                  a.as_out ? a.as_out + 4 * (size_t)s : nullptr);
+                                                                                  a.as_out ? a.as_out + 6 * (size_t)s : nullptr);
                 U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
                 solved_warm = (warm_rec != nullptr) && r.warm_valid;
                 work_tot += r.work;
