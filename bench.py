@@ -164,10 +164,11 @@ def cpu_baseline(workload: str, nscen: int, nsteps: int) -> dict | None:
 def measured_traffic(args):
     """HBM bytes per launch of the timed region from the PMC passes kept under profiles/ (rocprofv3 cannot run inside
     this process); only for a configuration those passes were taken on, else None."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if args.per_step_launch or not os.path.exists(path):
+    import glob
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))       # the latest set of passes
+    if args.per_step_launch or not tables:
         return None
-    with open(path) as fh:
+    with open(tables[-1]) as fh:
         table = json.load(fh)
     key = f"{args.workload}:B={args.batch or WORKLOADS[args.workload]['B']}:steps={args.steps}:warmup={args.warmup}"
     return table.get(key, {}).get("hbm_bytes_per_launch")

@@ -427,6 +427,11 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
+    // The output-feedback loop keeps the interior point.  On its way to the step every input of its problems is fixed by a
+    // bound (as many active bounds as inputs: the multiplier system of the active-set solve does not resolve there), and
+    // the sets it could solve later in the run are large enough that the method is no faster (measured on 8192
+    // scenarios x 300 steps with noise: 7.9 M scenario-steps/s without it, 7.7 M with it).
+    a.sh_T = nullptr;
     h->last_B = B;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;

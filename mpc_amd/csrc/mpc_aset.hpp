@@ -354,26 +354,29 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 
 // The size classes as functions of their own, each held to the registers its system needs (the attribute takes a
 // literal): what a function uses of the callee-saved registers it saves and restores on every call.
+#ifndef ASET_CLASS_LINKAGE
+#define ASET_CLASS_LINKAGE __noinline__
+#endif
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
                       double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds
 #define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds
 template <int N, int MM, int TAG>
-static __device__ __noinline__ AsetResult aset_run_small(MPC_ASET_ARGS)
+static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_small(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }
 template <int N, int MM, int TAG>
-static __device__ __noinline__ AsetResult aset_run_medium(MPC_ASET_ARGS)
+static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_medium(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }
 template <int N, int MM, int TAG>
-static __device__ __noinline__ AsetResult aset_run_large(MPC_ASET_ARGS)
+static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_large(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }
 template <int N, int MM, int TAG>
-static __device__ __noinline__ AsetResult aset_run_full(MPC_ASET_ARGS)
+static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_full(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }

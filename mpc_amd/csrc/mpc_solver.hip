@@ -136,9 +136,9 @@ static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_con
                                                                    int *as_o)
 {
     ConstrainedResult out = {0.0, 0.0, 0.0, 0, 0, 0, false};
-    // Back-off: a scenario whose active-set solves keep being handed on (large sets that jump from step to step, e.g. the
-    // output-feedback loop on a noisy estimate) tries the method again only after 1, 3, 7, 15 steps of interior point alone.
-    // The two counters travel in the scenario's record behind its validity flag.
+    // Back-off: a scenario whose active-set solves keep being handed on (the output-feedback loop on its way to the step:
+    // as many active bounds as inputs) tries the method again only after 1, 3, 7, 15 steps of interior point alone.  The
+    // two counters (steps to wait, failures in a row) travel in the scenario's record behind its validity flag.
     gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
     const int wait = bo ? __builtin_amdgcn_readfirstlane((int)bo[0]) : 0;       // wave-uniform
     if (T && wait > 0) {

@@ -69,15 +69,14 @@ def test_active_set_and_interior_point_agree_on_the_skidpad():
     assert np.abs(runs["auto"][0] - runs["interior_point"][0]).max() <= 1e-7
 
 
-def test_output_feedback_loop_with_noise_in_both_methods():
-    """BASELINE config 4 (simulator.py:206-281): the noisy output-feedback loop; same noise tensor, both methods.  On the
-    way to the step every input of these problems is fixed by a bound (full rate until the steering angle saturates, then
-    the angle bound to the end of the horizon: as many active bounds as inputs), which the multiplier system of the
-    active-set method does not resolve in double precision; its attempts are handed to the interior point and backed
-    off, so the two runs must agree and the attempts must stay a small share of the solves."""
+def test_output_feedback_loop_keeps_the_interior_point():
+    """BASELINE config 4 (simulator.py:206-281).  On the way to the step every input of the output-feedback problems is
+    fixed by a bound (full rate until the steering angle saturates, then the angle bound to the end of the horizon: as
+    many active bounds as inputs), which the multiplier system of the active-set method does not resolve in double
+    precision, so the fused loop does not attempt it: both settings of qp_method run the same arithmetic."""
     import torch
     from mpc_amd.batched import StepOFLBatch
-    B, n = 256, 80
+    B, n = 128, 60
     rng = np.random.default_rng(2)
     x = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, -10.0, 0.0]), (B, 1))
     x[:, 1] = rng.uniform(-0.2, 0.2, B)
@@ -88,14 +87,10 @@ def test_output_feedback_loop_with_noise_in_both_methods():
         sim = StepOFLBatch(50, 0.5, x, qp_method=method)
         xs, us, es = sim.run(n, record=True, meas_noise=noise)
         torch.cuda.synchronize()
-        out[method] = (xs.cpu().numpy(), us.cpu().numpy(), sim.status.cpu().numpy(), sim.ocp.stats())
-    assert (out["auto"][2] == out["interior_point"][2]).all() and np.isin(out["auto"][2], (0, 4)).all()
-    sa = out["auto"][3]
-    attempts = sa["n_active_set_solves"] + sa["n_active_set_too_large"] + sa["n_active_set_unsettled"]
-    assert 0 < attempts <= 0.25 * sa["n_constrained"]
-    ua, ub = out["auto"][1], out["interior_point"][1]
-    assert (np.abs(ua - ub) <= 10 * _tol(ub, 0.9)).all(), np.abs(ua - ub).max()
-    assert np.abs(out["auto"][0] - out["interior_point"][0]).max() <= 1e-7
+        out[method] = (xs, us, sim.ocp.stats())
+    assert torch.equal(out["auto"][1], out["interior_point"][1]) and torch.equal(out["auto"][0], out["interior_point"][0])
+    sa = out["auto"][2]
+    assert sa["n_active_set_solves"] + sa["n_active_set_too_large"] + sa["n_active_set_unsettled"] == 0 < sa["n_constrained"]
 
 
 def test_fused_launch_equals_per_step_launches_bit_for_bit():
