@@ -3,7 +3,7 @@ of the CPU checker (oracle.AcadosEmulation: SQP with the MIRROR-regularised Hess
 between calls) against the exact minimiser, (a) per step on the same problems along the C1 closed loop, (b) as two closed
 loops, one driven by each.  Study aid: it pins nothing (acados itself cannot run here).
 
-  python tools/acados_emulation_report.py [steps=3400] [N=50] [Tf=0.5]
+  python tests/report_acados_emulation.py [steps=3400] [N=50] [Tf=0.5]      (uses the checker: lives with the tests)
 """
 import sys
 

@@ -1,7 +1,7 @@
 """numpy (float64) emulation of the library's condensed interior point (mpc_ipm.hpp: interior_point) on a dumped
 closed-loop step of the LPV workload, for studying its iterates on the CPU.  Development tool, not product code.
 
-  python tools/ipm_emul.py gpurun_out/lpv_fail/cold_0.npz
+  python tests/study_ipm_emulation.py gpurun_out/lpv_fail/cold_0.npz      (uses the checker: lives with the tests)
 """
 import sys
 

@@ -25,8 +25,8 @@ def test_regularised_sqp_step_reduces_to_the_exact_solve_without_regularisation(
 
 def test_emulated_reference_solver_stays_close_to_the_minimiser_on_the_skidpad_loop():
     import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from acados_emulation_report import run
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from report_acados_emulation import run
     r = run(steps=500, N=50, Tf=0.5, kind="L")
     assert r["sqp_iterations_histogram"][1] == 499 and r["sqp_iterations_histogram"][2] == 1   # two iterations on the first call only
     assert 1e-7 < r["max_abs_du0"] < 5e-3           # the regularisation is felt in the inputs, in their 3rd-4th digit
