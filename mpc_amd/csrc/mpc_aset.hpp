@@ -181,9 +181,8 @@ struct AsetResult {
 // (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
 // ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
 // written with the result when the solve succeeds (or NULL); lds: the wave's 4 (N + 1) doubles of references and speeds.
-// Not inlined, like the interior point: the registers of a size class (the row of its multiplier system) stay out of the
-// per-step path's allocation, and the smallest class, which serves most solves, saves and restores few of them.  TAG
-// gives every calling kernel its own copies with that kernel's register budget.
+// Inlined into the caller's one non-inlined function of the constrained step (solve_constrained in mpc_solver.hip), whose
+// registers stay out of the per-step path's allocation.
 template <int N, int MM>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
@@ -352,10 +351,10 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     return out;
 }
 
-// The size classes as functions of their own, each held to the registers its system needs (the attribute takes a
-// literal): what a function uses of the callee-saved registers it saves and restores on every call.
+// The size classes by name.  They are part of the caller's one non-inlined function of the constrained step: a call level
+// of their own costs another save and restore of the callee-saved registers per solve (measured: 2% of the c2 window).
 #ifndef ASET_CLASS_LINKAGE
-#define ASET_CLASS_LINKAGE __noinline__
+#define ASET_CLASS_LINKAGE __forceinline__
 #endif
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
                       double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds

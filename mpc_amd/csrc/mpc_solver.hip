@@ -140,7 +140,9 @@ static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_con
     // as many active bounds as inputs) tries the method again only after 1, 3, 7, 15 steps of interior point alone.  The
     // two counters (steps to wait, failures in a row) travel in the scenario's record behind its validity flag.
     gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
-    const int wait = bo ? __builtin_amdgcn_readfirstlane((int)bo[0]) : 0;       // wave-uniform
+    double bo0 = 0.0, bo1 = 0.0;
+    if (bo) { bo0 = bo[0]; bo1 = bo[1]; }                                       // one round trip for both
+    const int wait = __builtin_amdgcn_readfirstlane((int)bo0);                  // wave-uniform
     if (T && wait > 0) {
         if (lane == 0) bo[0] = (double)(wait - 1);
     } else if (T) {
@@ -148,16 +150,17 @@ static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_con
                                                       prm.warm_mode != 0, lds);
         out.work = r.iters;
         // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
-        // registers of the step loop they would crowd the unconstrained steps
+        // registers of the step loop they would crowd the unconstrained steps.  (Atomics without a return value: nothing
+        // waits for them.)
         if (as_o && lane == 0) {
-            as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3] += 1;
-            as_o[1] += r.iters;
-            as_o[4] += (r.flops + 32) >> 6;
+            atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
+            atomicAdd(&as_o[1], r.iters);
+            atomicAdd(&as_o[4], (r.flops + 32) >> 6);
         }
         if (bo && lane == 0) {
-            const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo[1] + 1, 4);
-            bo[1] = (double)streak;
-            bo[0] = (double)((1 << streak) - 1);
+            const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
+            if ((double)streak != bo1) bo[1] = (double)streak;
+            if (streak) bo[0] = (double)((1 << streak) - 1);
         }
         if (r.why == ASET_SOLVED) {
             out.U = r.U; out.warm_valid = prm.warm != nullptr;
