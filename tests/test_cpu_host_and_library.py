@@ -186,3 +186,27 @@ def test_discrete_flag_behaves_like_the_reference_constructors():
     a = LPVOcp(10, 0.1, discrete=False, _host_only=True)
     b = LPVOcp(10, 0.1, _host_only=True)
     assert a.discrete is False and np.array_equal(a.W, b.W) and np.array_equal(a.W_e, b.W_e)
+
+
+def test_create_rejects_bad_definitions_before_touching_a_device(lib_path):
+    """mpc_create checks the controller definition first (no HIP call has happened when it refuses): unknown kind, layout
+    or QP method, non-positive bounds and weights, horizons outside 2..128."""
+    from mpc_amd import _lib
+    from mpc_amd.controllers import LOcp
+    lib = _lib.load()
+    good = LOcp(50, 0.5, _host_only=True)._make_config()
+
+    def refused(**changes):
+        cfg = _lib.MpcConfig.from_buffer_copy(good)
+        for k, v in changes.items():
+            setattr(cfg, k, v)
+        h = ctypes.c_void_p()
+        rc = lib.mpc_create(ctypes.byref(cfg), ctypes.byref(h))
+        assert not h.value
+        return rc, lib.mpc_last_error(None).decode()
+
+    for changes, word in (({"kind": 9}, "kind"), ({"N": 1}, "horizon"), ({"N": 129}, "horizon"), ({"B": 0}, "B >= 1"),
+                          ({"max_rate": 0.0}, "max_rate"), ({"max_steering": -0.3}, "max_rate"), ({"solver_layout": 5}, "solver_layout"),
+                          ({"qp_method": 2}, "qp_method"), ({"qp_method": -1}, "qp_method"), ({"step_ramp_length": -1.0}, "step_ramp_length")):
+        rc, msg = refused(**changes)
+        assert rc == -1 and word in msg, (changes, rc, msg)
