@@ -3,7 +3,7 @@ mpc_amd/csrc/mpc_aset.hpp on the c2 closed loop: from the previous step's active
 solves settle, and in how many iterations, when every wrong-signed and every violated bound is exchanged at once ("pdas")
 or one bound leaves and one enters per iteration ("single").  Not collected by pytest.
 
-  python tests/study_active_set_rules.py <scenarios> <steps> <iteration cap> pdas|single|hybrid
+  python tests/study_active_set_rules.py <scenarios> <steps> <iteration cap> pdas|single|pertype|hybrid
 """
 import sys
 import numpy as np
@@ -70,6 +70,16 @@ for b in range(B):
                 if MODE == "pdas" or (MODE == "hybrid" and cold and it == 0):
                     nau &= ~bad; nal &= ~bad
                     nau |= (~au & ~al & (vv > up + 1e-12)); nal |= (~au & ~al & (vv < lo - 1e-12))
+                elif MODE == "pertype":
+                    # one bound out and one in per kind of bound (input bounds, steering bounds)
+                    for sl in (slice(0, N), slice(N, 2 * N - 1)):
+                        if bad[sl].any():
+                            score = np.where(bad[sl], np.where(skipped[sl], 1e300, np.abs(lamv[sl]) * wid[sl]), -1)
+                            j = sl.start + int(np.argmax(score)); nau[j] = False; nal[j] = False
+                        if (viol[sl] > 0).any():
+                            j = sl.start + int(np.argmax(viol[sl]))
+                            if vv[j] > up[j]: nau[j] = True
+                            else: nal[j] = True
                 else:
                     if bad.any():
                         score = np.where(bad, np.where(skipped, 1e300, np.abs(lamv) * wid), -1)
