@@ -13,7 +13,7 @@ KIND = {"L": 0, "OFL": 1, "LPV": 2, "NL": 3}
 PLANNER_SKIDPAD, PLANNER_STEP = 0, 1
 MAX_HORIZON = 128
 LAYOUT = {"auto": 0, "wave": 1, "lane": 2}
-QP_METHOD = {"auto": 0, "interior_point": 1}
+QP_METHOD = {"auto": 0, "interior_point": 1, "active_set": 2}
 
 
 class MpcConfig(C.Structure):

@@ -98,7 +98,7 @@ static const char *check_config(const mpc_config *cfg)
     } else if (!(cfg->w[6] > 0.0)) return "input weight R*r must be positive (strict convexity)";
     if (cfg->solver_layout < MPC_LAYOUT_AUTO || cfg->solver_layout > MPC_LAYOUT_LANE) return "unknown solver_layout";
     if (cfg->solver_layout == MPC_LAYOUT_LANE && cfg->kind == MPC_KIND_NL) return "the NL controller has no lane-per-scenario kernel";
-    if (cfg->qp_method < MPC_QP_AUTO || cfg->qp_method > MPC_QP_INTERIOR_POINT) return "unknown qp_method";
+    if (cfg->qp_method < MPC_QP_AUTO || cfg->qp_method > MPC_QP_ACTIVE_SET) return "unknown qp_method";
     if (!(cfg->max_rate > 0.0) || !(cfg->max_steering > 0.0)) return "max_rate and max_steering must be positive";
     return nullptr;
 }
@@ -427,11 +427,12 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    // The output-feedback loop keeps the interior point.  On its way to the step every input of its problems is fixed by a
-    // bound (as many active bounds as inputs: the multiplier system of the active-set solve does not resolve there), and
-    // the sets it could solve later in the run are large enough that the method is no faster (measured on 8192
-    // scenarios x 300 steps with noise: 7.9 M scenario-steps/s without it, 7.7 M with it).
-    a.sh_T = nullptr;
+    // With MPC_QP_AUTO the output-feedback loop keeps the interior point: on noisy estimates (the workload this entry point
+    // exists for) the active sets are large and jump from step to step, a third of the attempts are handed on, and the
+    // method is no faster (measured on 8192 scenarios x 300 steps with the EKF's measurement noise: 7.9 M scenario-steps/s
+    // without it, 7.5 M with it).  Without noise the sets move one stage per step and it is 2.3 times faster
+    // (256 scenarios x 80 steps: 9.1 ms against 20.5 ms): MPC_QP_ACTIVE_SET asks for it here too.
+    if (h->cfg.qp_method != MPC_QP_ACTIVE_SET) a.sh_T = nullptr;
     h->last_B = B;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;

@@ -164,6 +164,30 @@ __device__ __forceinline__ double aset_combine(const aset_gdouble *Tg, int my_ci
     return acc + acc1;
 }
 
+// value of `v` in lane `src` (per-lane index, 0..63) through the LDS crossbar
+__device__ __forceinline__ int lane_read(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ double lane_read(double v, int src)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// The multiplier of this lane's steering bound from the multipliers of the rows the system was solved with.  A run of
+// active steering bounds k1..k2 (same side) enters the system as the prefix-sum row of k1 (multiplier mu) and the unit rows
+// of the inputs k1+1..k2 (multipliers eta_j): the same constraints, but rows that do not grow ever more parallel along
+// the run.  sum_k nu_k prefix_k = mu prefix_k1 + sum_j eta_j e_j  gives  nu_j = (eta_j - eta_{j+1}) / dt  inside the run
+// (eta beyond its end = 0) and  nu_k1 = mu - eta_{k1+1} / dt.
+__device__ __forceinline__ double aset_steer_multiplier(int lane, int ad, bool in_run, double tm, double dt)
+{
+    const int nxt = min(lane + 1, WAVE - 1);
+    const bool next_in_run = lane < WAVE - 1 && lane_read((int)in_run, nxt) != 0;
+    const double tn = lane_read(tm, nxt);
+    const double eta_next = next_in_run ? tn : 0.0;
+    if (ad == 0) return 0.0;
+    return in_run ? (tm - eta_next) / dt : tm - eta_next / dt;
+}
+
 enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 };
 
 struct AsetResult {
@@ -201,11 +225,23 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 
     SmallLdl<MM> ldl;
     AsetResult out = {0.0, au, ad, it0, fl0, ASET_UNSETTLED};
-    double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0;
+    double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0, tm = 0.0, b_run = 0.0;
     int my_cid = 0, m = 0, rank_u = 0, rank_d = 0;
-    bool converged = false;
+    bool converged = false, in_run = false;
 #pragma unroll 1
     for (int it = it0; it < aset_iter_cap(MM); it++) {
+        // a steering bound whose predecessor stage is active on the same side enters as "this input = the step between
+        // the two bounds" (0 unless the bound was widened): see aset_steer_multiplier.  Such an input cannot sit at its
+        // rate bound as well (the step between two steering bounds is never the full rate): that bound leaves the set.
+        {
+            const int prv = max(lane - 1, 0);
+            const double b_d = ad > 0 ? up_d : lo_d;
+            const int ad_prev = lane > 0 ? lane_read(ad, prv) : 0;
+            const double b_prev = lane_read(b_d, prv);
+            in_run = ad != 0 && ad_prev == ad;
+            b_run = in_run ? (b_d - b_prev) / dt : b_d;
+            if (in_run) au = 0;
+        }
         const unsigned long long mask_u = __ballot(au != 0), mask_d = __ballot(ad != 0);
         const int m_u = __popcll(mask_u);
         m = m_u + __popcll(mask_d);
@@ -217,7 +253,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         rank_d = m_u + __popcll(mask_d & below);
         // the active bounds in lanes 0..m-1: which bound, and by how much the unconstrained minimiser misses it
         if (au != 0) { cid_l[rank_u] = lane; val_l[rank_u] = Uu - (au > 0 ? umax : -umax); }
-        if (ad != 0) { cid_l[rank_d] = N + lane; val_l[rank_d] = vdu - (ad > 0 ? up_d : lo_d); }
+        if (ad != 0) { cid_l[rank_d] = in_run ? lane : N + lane; val_l[rank_d] = (in_run ? Uu : vdu) - b_run; }
         wave_sync();
         const bool act = lane < m;
         my_cid = act ? cid_l[lane] : 0;
@@ -240,8 +276,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         if (act) val_l[lane] = ldl.dinv == 0.0 ? __builtin_nan("") : nu;
         wave_sync();
         nu_u = au != 0 ? val_l[rank_u] : 0.0;
-        nu_d = ad != 0 ? val_l[rank_d] : 0.0;
+        tm = ad != 0 ? val_l[rank_d] : 0.0;
         wave_sync();
+        nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
         // U = Uu - sum_s nu_s * (column of inv(H) [I P'] of bound s)
         U = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, nu, m, lc, Uu, -1.0) : 0.0;
         const double vd = dt * incl_prefix(U, lane);
@@ -312,7 +349,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         const double vdc = dt * incl_prefix(valid ? U : 0.0, lane);
         // right-hand side E z - (E U - b): the correction also closes what the point misses its active bounds by
         if (au != 0) val_l[rank_u] = z - (U - (au > 0 ? umax : -umax));
-        if (ad != 0) val_l[rank_d] = pz - (vdc - (ad > 0 ? up_d : lo_d));
+        if (ad != 0) val_l[rank_d] = in_run ? z - (U - b_run) : pz - (vdc - b_run);
         wave_sync();
         const double ez = lane < m ? val_l[lane] : 0.0;
         wave_sync();
@@ -320,8 +357,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         if (lane < m) val_l[lane] = dn;
         wave_sync();
         if (au != 0) nu_u -= val_l[rank_u];
-        if (ad != 0) nu_d -= val_l[rank_d];
+        if (ad != 0) tm -= val_l[rank_d];
         wave_sync();
+        nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
         const double corr = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, dn, m, lc, -z, 1.0) : 0.0;
         U += corr;
         const double cmax = wave_max(fabs(corr));

@@ -207,6 +207,6 @@ def test_create_rejects_bad_definitions_before_touching_a_device(lib_path):
 
     for changes, word in (({"kind": 9}, "kind"), ({"N": 1}, "horizon"), ({"N": 129}, "horizon"), ({"B": 0}, "B >= 1"),
                           ({"max_rate": 0.0}, "max_rate"), ({"max_steering": -0.3}, "max_rate"), ({"solver_layout": 5}, "solver_layout"),
-                          ({"qp_method": 2}, "qp_method"), ({"qp_method": -1}, "qp_method"), ({"step_ramp_length": -1.0}, "step_ramp_length")):
+                          ({"qp_method": 3}, "qp_method"), ({"qp_method": -1}, "qp_method"), ({"step_ramp_length": -1.0}, "step_ramp_length")):
         rc, msg = refused(**changes)
         assert rc == -1 and word in msg, (changes, rc, msg)

@@ -69,28 +69,38 @@ def test_active_set_and_interior_point_agree_on_the_skidpad():
     assert np.abs(runs["auto"][0] - runs["interior_point"][0]).max() <= 1e-7
 
 
-def test_output_feedback_loop_keeps_the_interior_point():
-    """BASELINE config 4 (simulator.py:206-281).  On the way to the step every input of the output-feedback problems is
-    fixed by a bound (full rate until the steering angle saturates, then the angle bound to the end of the horizon: as
-    many active bounds as inputs), which the multiplier system of the active-set method does not resolve in double
-    precision, so the fused loop does not attempt it: both settings of qp_method run the same arithmetic."""
+def test_output_feedback_loop_methods(orc64):
+    """The fused output-feedback loop (simulator.py:206-281).  On the way to the step every input of its problems is fixed
+    by a bound (full rate until the steering angle saturates, then the angle bound to the end of the horizon: as many
+    active bounds as inputs); a run of active steering bounds enters the multiplier system as unit rows, which keeps that
+    system as well conditioned as inv(H).  qp_method "auto" keeps the interior point in this loop (its measurement noise
+    makes the sets jump), "active_set" asks for the active-set solve: without noise nearly every solve ends there, and
+    both follow the checker's loop."""
     import torch
+    from oracle import oracle as O
     from mpc_amd.batched import StepOFLBatch
-    B, n = 128, 60
+    B, n = 64, 60
     rng = np.random.default_rng(2)
     x = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, -10.0, 0.0]), (B, 1))
     x[:, 1] = rng.uniform(-0.2, 0.2, B)
-    sigma = np.array([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01])                           # continuous_dynamics.py:68-72
-    noise = rng.standard_normal((n, B, 7)) * sigma * 0.2
+    cfg = O.make_cfg("OFL", 50, 0.5)
+    est = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (B, 1))
+    P = np.tile(np.diag(O.EKF_P0_DIAG), (B, 1, 1))
+    xr = x.copy()
+    u_ref, x_ref, e_ref, st_ref, _ = orc64.ofl_run(cfg, xr, est, P, 15.0, n)
     out = {}
-    for method in ("auto", "interior_point"):
+    for method in ("auto", "interior_point", "active_set"):
         sim = StepOFLBatch(50, 0.5, x, qp_method=method)
-        xs, us, es = sim.run(n, record=True, meas_noise=noise)
+        xs, us, es = sim.run(n, record=True)
         torch.cuda.synchronize()
-        out[method] = (xs, us, sim.ocp.stats())
-    assert torch.equal(out["auto"][1], out["interior_point"][1]) and torch.equal(out["auto"][0], out["interior_point"][0])
-    sa = out["auto"][2]
-    assert sa["n_active_set_solves"] + sa["n_active_set_too_large"] + sa["n_active_set_unsettled"] == 0 < sa["n_constrained"]
+        assert (sim.status.cpu().numpy() == st_ref).all()
+        out[method] = (xs.cpu().numpy(), us.cpu().numpy(), sim.ocp.stats())
+        assert (np.abs(out[method][1] - u_ref) <= 10 * _tol(u_ref, cfg[10])).all(), (method, np.abs(out[method][1] - u_ref).max())
+        assert np.abs(out[method][0] - x_ref).max() <= 1e-7, method
+    assert np.array_equal(out["auto"][1], out["interior_point"][1])              # the same arithmetic
+    sa = out["active_set"][2]
+    assert out["auto"][2]["n_active_set_solves"] == 0 and sa["n_active_set_solves"] >= 0.8 * sa["n_constrained"] > 0
+    assert sa["sum_iterations"] < 0.25 * out["interior_point"][2]["sum_iterations"]
 
 
 def test_fused_launch_equals_per_step_launches_bit_for_bit():
