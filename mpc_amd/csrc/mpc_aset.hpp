@@ -38,6 +38,21 @@ constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a
 #define ASET_DU_EARLY 1e-6
 #endif
 constexpr double ASET_DU_TOL = 1e-10;
+// entries of a column of H (or of its inverse) requested at a time in the certificate: one memory round trip per chunk, two
+// registers per entry while it waits
+// rows of the table requested at a time when the inputs are updated (smallest size class / the others)
+#ifndef ASET_ROWS_SMALL
+#define ASET_ROWS_SMALL 8
+#endif
+#ifndef ASET_ROWS_LARGE
+#define ASET_ROWS_LARGE 8
+#endif
+#ifndef ASET_GATHER_CHUNK
+#define ASET_GATHER_CHUNK 16
+#endif
+#ifndef ASET_COL_CHUNK
+#define ASET_COL_CHUNK 10
+#endif
 // A pivot below this fraction of the row's own diagonal entry: the bound's row depends on the rows before it
 constexpr double ASET_PIV_MIN = 1e-9;
 
@@ -263,11 +278,23 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         const unsigned rowoff = (unsigned)my_cid * LD;
         const double diag0 = act ? Tg[rowoff + (unsigned)my_cid] : 1.0;
         const int lane_o = opaque_int(lane);
+        // (entries requested ASET_GATHER_CHUNK at a time: with all of a large class in flight next to the row itself the
+        // registers run out)
 #pragma unroll
-        for (int s = 0; s < MM; s++) {
-            const int cs = __builtin_amdgcn_readlane(my_cid, s);
-            const double t = (Tg + cs)[rowoff];
-            ldl.row[s] = (act && s < m) ? t : (lane_o == s ? 1.0 : 0.0);
+        for (int s0 = 0; s0 < MM; s0 += ASET_GATHER_CHUNK) {
+            double t[ASET_GATHER_CHUNK];
+#pragma unroll
+            for (int g = 0; g < ASET_GATHER_CHUNK; g++) {
+                if (s0 + g < MM) {
+                    const int cs = __builtin_amdgcn_readlane(my_cid, s0 + g);
+                    t[g] = (Tg + cs)[rowoff];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < ASET_GATHER_CHUNK; g++)
+                if (s0 + g < MM) ldl.row[s0 + g] = (act && s0 + g < m) ? t[g] : (lane_o == s0 + g ? 1.0 : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         ldl.template factor<USE_LDS>(lane, diag0, bc);
         nu = ldl.solve(my_d, lane);
@@ -280,7 +307,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         wave_sync();
         nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
         // U = Uu - sum_s nu_s * (column of inv(H) [I P'] of bound s)
-        U = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, nu, m, lc, Uu, -1.0) : 0.0;
+        U = valid ? aset_combine<LD, (MM <= 16 ? ASET_ROWS_SMALL : ASET_ROWS_LARGE)>(Tg, my_cid, nu, m, lc, Uu, -1.0) : 0.0;
         const double vd = dt * incl_prefix(U, lane);
         // next set: the one bound whose multiplier has the wrong sign by the most (or whose row was left out) goes, the
         // one bound the new point violates by the most comes in.  (Exchanging every such bound at once is quicker when
@@ -317,32 +344,38 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     for (int pass = 0; pass < 3 && !certified; pass++) {
         out.flops += 4 * N * N + 2 * m * m + 2 * m * N;
         const double dU = valid ? U - Uu : 0.0;
-        // (a column of H, then one of inv(H): every entry requested before the first is used, one round trip each)
+        // (a column of H, then one of inv(H), in chunks of ASET_COL_CHUNK entries requested before the first is used)
         double hu0 = 0.0, hu1 = 0.0;
-        {
-            double hc[N];
 #pragma unroll
-            for (int j = 0; j < N; j++) hc[j] = Hg[j * N + lc];
+        for (int c0 = 0; c0 < N; c0 += ASET_COL_CHUNK) {
+            double hc[ASET_COL_CHUNK];
+#pragma unroll
+            for (int j = 0; j < ASET_COL_CHUNK; j++)
+                if (c0 + j < N) hc[j] = Hg[(c0 + j) * N + lc];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < N; j += 2) {
-                hu0 = fma(hc[j], bcast(dU, j), hu0);
-                if (j + 1 < N) hu1 = fma(hc[j + 1], bcast(dU, j + 1), hu1);
+            for (int j = 0; j < ASET_COL_CHUNK; j += 2) {
+                if (c0 + j < N) hu0 = fma(hc[j], bcast(dU, c0 + j), hu0);
+                if (c0 + j + 1 < N) hu1 = fma(hc[j + 1], bcast(dU, c0 + j + 1), hu1);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double frc = nu_u + dt * incl_suffix(validd ? nu_d : 0.0, lane);      // (E' nu)[lane]
         const double r = valid ? hu0 + hu1 + frc : 0.0;
         double z0 = 0.0, z1 = 0.0;
-        {
-            double gc[N];
 #pragma unroll
-            for (int j = 0; j < N; j++) gc[j] = Tg[j * LD + lc];
+        for (int c0 = 0; c0 < N; c0 += ASET_COL_CHUNK) {
+            double gc[ASET_COL_CHUNK];
+#pragma unroll
+            for (int j = 0; j < ASET_COL_CHUNK; j++)
+                if (c0 + j < N) gc[j] = Tg[(c0 + j) * LD + lc];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < N; j += 2) {
-                z0 = fma(gc[j], bcast(r, j), z0);
-                if (j + 1 < N) z1 = fma(gc[j + 1], bcast(r, j + 1), z1);
+            for (int j = 0; j < ASET_COL_CHUNK; j += 2) {
+                if (c0 + j < N) z0 = fma(gc[j], bcast(r, c0 + j), z0);
+                if (c0 + j + 1 < N) z1 = fma(gc[j + 1], bcast(r, c0 + j + 1), z1);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double z = valid ? z0 + z1 : 0.0;
         const double pz = dt * incl_prefix(z, lane);
@@ -360,7 +393,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         if (ad != 0) tm -= val_l[rank_d];
         wave_sync();
         nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
-        const double corr = valid ? aset_combine<LD, (MM <= 16 ? 16 : 8)>(Tg, my_cid, dn, m, lc, -z, 1.0) : 0.0;
+        const double corr = valid ? aset_combine<LD, (MM <= 16 ? ASET_ROWS_SMALL : ASET_ROWS_LARGE)>(Tg, my_cid, dn, m, lc, -z, 1.0) : 0.0;
         U += corr;
         const double cmax = wave_max(fabs(corr));
         certified = cmax <= (pass == 0 ? ASET_DU_EARLY : ASET_DU_TOL) * umax;
