@@ -123,7 +123,8 @@ int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario);
 
 /* Fixed-model cache for the linear controllers (kind L / OFL): condenses the horizon once for "every stage at
  * speed vx" (the skidpad planner hands the controller a constant speed profile, path_planning.py:238-240) and
- * caches H and inv(H) times every way the gradient depends on the step's data.  Scenarios whose speed profile
+ * caches H and inv(H) times every way the gradient depends on the step's data, and (unless qp_method is
+ * MPC_QP_INTERIOR_POINT) the table [I; P] inv(H) [I P'] of the active-set solve (P = the steering rows; (2N)^2 doubles).  Scenarios whose speed profile
  * is not exactly vx still take the per-scenario condensing path inside the same launch, unless `exclusive` is
  * set: then the caller promises that every scenario runs at vx, a leaner kernel without the per-scenario path is
  * launched, and a scenario that breaks the promise is not solved but reported with status 3.  vx = NaN switches
