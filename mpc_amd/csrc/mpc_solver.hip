@@ -123,6 +123,9 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 // A solve of the fixed-model path whose unconstrained minimiser Uu violates a bound: the active-set method where the table
 // T is at hand, the interior point for what it hands on.  One call site in the per-step loop (a function of its own:
 // what the step loop keeps in registers is saved around it only on the steps that get here).
+#ifndef MPC_CONSTRAINED_LINKAGE
+#define MPC_CONSTRAINED_LINKAGE __noinline__ __attribute__((cold))
+#endif
 struct ConstrainedResult {
     double U, mu, res;
     int iters, status;           // interior-point iterations and status
@@ -131,7 +134,7 @@ struct ConstrainedResult {
 };
 
 template <int N, int TAG>
-static __device__ __noinline__ __attribute__((cold)) ConstrainedResult solve_constrained(IpmParams prm, int lane, const double *Hm, const double *T,
+static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(IpmParams prm, int lane, const double *Hm, const double *T,
                                                                    double Uu, double vdu, double up_d, double lo_d, double *lds,
                                                                    int *as_o)
 {
