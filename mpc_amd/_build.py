@@ -28,8 +28,17 @@ def _hipcc() -> str:
     return exe
 
 
+DEV_MARK = os.path.join(LIB_DIR, "DEVELOPER_BUILD")      # left by a build with MPC_DEV_* set: the next plain build redoes it
+
+
+def _dev_env() -> bool:
+    return bool(os.environ.get("MPC_DEV_HORIZONS") or os.environ.get("MPC_DEV_DEFINES"))
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    if os.path.exists(DEV_MARK) and not _dev_env():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
@@ -65,6 +74,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    if _dev_env():
+        open(DEV_MARK, "w").write("built with MPC_DEV_* set: not every horizon is instantiated\n")
+    elif os.path.exists(DEV_MARK):
+        os.remove(DEV_MARK)
     return LIB_PATH
 
 
