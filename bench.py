@@ -187,13 +187,13 @@ WORKLOADS = {
 }
 
 
-def build_workload(name: str, B: int, rank: int, dev, steps_total: int):
+def build_workload(name: str, B: int, rank: int, dev, steps_total: int, qp_method: str = "auto"):
     """Returns (run(n), controller, status tensor, iters setter)."""
     import torch
     from mpc_amd.batched import SkidpadBatch, StepOFLBatch
     w = WORKLOADS[name]
     if name == "c2":
-        sim = SkidpadBatch(w["N"], w["Tf"], initial_states(B, rank), model="L", device=dev)
+        sim = SkidpadBatch(w["N"], w["Tf"], initial_states(B, rank), model="L", device=dev, qp_method=qp_method)
         return sim, sim.run
     if name == "c3":
         st = initial_states(B, 1000 + rank)
@@ -206,7 +206,7 @@ def build_workload(name: str, B: int, rank: int, dev, steps_total: int):
         true0[:, 9] = rng.uniform(-12.0, -8.0, B)
         est0 = np.tile(np.array([-5.0, 0.0, 1.0, 0.0, 15.0, 0.0, 0.0, 0.0, 0.0, 0.0]), (B, 1))
         est0[:, 1] += rng.normal(0, 0.05, B); est0[:, 5] += rng.normal(0, 0.02, B)
-        sim = StepOFLBatch(w["N"], w["Tf"], true0, est0, device=dev)
+        sim = StepOFLBatch(w["N"], w["Tf"], true0, est0, device=dev, qp_method=qp_method)
         gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
         sigma = torch.tensor([0.3, 0.3, 0.1, 0.1, 0.1, 0.01, 0.01], dtype=torch.float64, device=dev)
         noise = torch.randn((steps_total, B, 7), dtype=torch.float64, device=dev, generator=gen) * sigma
@@ -291,6 +291,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--batch", type=int, default=None, help="scenarios per GPU (default: the workload's)")
+    ap.add_argument("--qp-method", choices=["auto", "interior_point", "active_set"], default="auto",
+                    help="c2 / c4: how constrained solves of the fixed-model path are finished (mpc_config.qp_method)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-step-launch", action="store_true", help="one kernel launch per closed-loop step in the timed region")
     ap.add_argument("--latency-launches", type=int, default=None, help="single-step launches timed after the run (default 200; 0 = none)")
@@ -331,7 +333,7 @@ def main() -> None:
     N = wl["N"]
     nlat = args.latency_launches if args.latency_launches is not None else (0 if args.per_step_launch else (50 if args.workload == "c5" else 200))
     extra = nlat + (1000 if args.workload == "c2" else 0)
-    sim, run = build_workload(args.workload, B, rank, dev, args.steps + args.warmup + settle + extra)
+    sim, run = build_workload(args.workload, B, rank, dev, args.steps + args.warmup + settle + extra, args.qp_method)
     if settle:
         run(settle)
 

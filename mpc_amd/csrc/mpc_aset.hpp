@@ -30,7 +30,10 @@ typedef __attribute__((address_space(3))) int aset_lint;
 // iteration caps (counted over the whole solve): an iteration of the largest size class costs about as much as one of
 // the interior point, so a set of that size that has not settled after a few exchanges is handed on
 constexpr int ASET_MAX_ITER = 10;
-__device__ __forceinline__ constexpr int aset_iter_cap(int MM) { return MM <= 32 ? 10 : 6; }
+#ifndef ASET_CAP_LARGE
+#define ASET_CAP_LARGE 6
+#endif
+__device__ __forceinline__ constexpr int aset_iter_cap(int MM) { return MM <= 32 ? 10 : ASET_CAP_LARGE; }
 constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a previous set starts from
 // sizes of the certificate's corrections relative to the input bound: a first correction below EARLY is taken as final
 // (what is left after it is smaller by the accuracy of the cached inverse), a later one has to come out below TOL
