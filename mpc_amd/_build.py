@@ -14,7 +14,7 @@ SOURCES = ["mpc_solver.hip", "mpc_generic.hip", "mpc_lanes.hip", "mpc_nl.hip", "
 # second builds of a source with other macros: (source, object name, flags).  mpc_lanes.hip without the longitudinal
 # position in its recursions (see LANE_X0 there).
 VARIANTS = [("mpc_lanes.hip", "mpc_lanes_nopx.o", ["-DLANE_X0=1"])]
-HEADERS = ["mpc_device.hpp", "mpc_wave.hpp", "mpc_ipm.hpp", "mpc_kernels.h", os.path.join("..", "..", "include", "mpc_amd.h")]
+HEADERS = ["mpc_device.hpp", "mpc_wave.hpp", "mpc_ipm.hpp", "mpc_aset.hpp", "mpc_kernels.h", os.path.join("..", "..", "include", "mpc_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Machine LICM hoists the literal constants of the inlined math routines out of the in-kernel step loop and then
 # spills them to scratch; rematerialising them in place keeps the per-step hot path free of scratch traffic.

@@ -138,10 +138,13 @@ __device__ __forceinline__ void steer_bounds(double d0, double dmax, double umax
 constexpr int IPM_SAFE_AFTER = 25;
 constexpr double IPM_WARM_RES_MAX = 0.05;   // largest relative residual a warm start is accepted with
 
+#ifndef MPC_NOTAIL
+#define MPC_NOTAIL __attribute__((not_tail_called))
+#endif
 // TAG gives every calling kernel its own copy (internal linkage), so that the copy inherits that kernel's occupancy
 // target as its register budget instead of the loosest budget among all callers.
 template <int N, int TAG>
-static __device__ __noinline__ IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double up_d,
+static __device__ __noinline__ MPC_NOTAIL IpmResult interior_point(IpmParams prm, int lane, const double *Hm, double g, double up_d,
                                                  double lo_d, ldouble *bc)
 {
     Newton<N> nt;

@@ -124,7 +124,7 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 // T is at hand, the interior point for what it hands on.  One call site in the per-step loop (a function of its own:
 // what the step loop keeps in registers is saved around it only on the steps that get here).
 #ifndef MPC_CONSTRAINED_LINKAGE
-#define MPC_CONSTRAINED_LINKAGE __noinline__ __attribute__((cold))
+#define MPC_CONSTRAINED_LINKAGE __noinline__ __attribute__((cold)) MPC_NOTAIL
 #endif
 struct ConstrainedResult {
     double U, mu, res;
