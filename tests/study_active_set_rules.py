@@ -3,7 +3,7 @@ mpc_amd/csrc/mpc_aset.hpp on the c2 closed loop: from the previous step's active
 solves settle, and in how many iterations, when every wrong-signed and every violated bound is exchanged at once ("pdas")
 or one bound leaves and one enters per iteration ("single").  Not collected by pytest.
 
-  python tests/study_active_set_rules.py <scenarios> <steps> <iteration cap> pdas|single|pertype|hybrid
+  python tests/study_active_set_rules.py <scenarios> <steps> <iteration cap> pdas|single|pertype|hybrid [moved|union|stay]
 """
 import sys
 import numpy as np
@@ -15,6 +15,7 @@ orc = O.Oracle("f64")
 N, Tf = 50, 0.5; dt = Tf / N
 cfg = O.make_cfg("L", N, Tf)
 B = int(sys.argv[1]); nst = int(sys.argv[2]); MAXIT = int(sys.argv[3]); MODE = sys.argv[4]
+START = sys.argv[5] if len(sys.argv) > 5 else "moved"     # starting set: the previous one moved a stage, "union" with where it was, or "stay"
 st = initial_states(4096, 0)[:B]
 umax, dmax = cfg[10], cfg[9]
 wid = np.concatenate([np.full(N, umax), np.full(N - 1, dmax)])
@@ -55,6 +56,10 @@ for b in range(B):
                 pu, pl = prev
                 au = np.concatenate([pu[1:N], pu[N-1:N], pu[N+1:], pu[-1:]])
                 al = np.concatenate([pl[1:N], pl[N-1:N], pl[N+1:], pl[-1:]])
+                if START == "union":        # the moved set and the set where it was: runs keep their far end
+                    au, al = (au | pu) & ~pl, (al | pl) & ~pu
+                elif START == "stay":
+                    au, al = pu.copy(), pl.copy()
                 cold = False
             else:
                 au = vu > up; al = vu < lo; cold = True
