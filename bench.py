@@ -64,7 +64,7 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
     outputs, 5N^3/3; gradient and H*U 4N^2; LDL' N^3/3 + 2N^2.
     Every interior-point iteration of c2/c4/c5 adds ipm_flops(N); the active-set solves of c2/c4 add the count the kernel
     keeps for them (`extra`, per scenario-step: LDL' of the m x m multiplier system m^3/3, two solves 2m^2, the update of
-    the inputs 2mN, scans ~20N per iteration; 4N^2 + 2m^2 + 2mN per certificate pass)."""
+    the inputs 2mN, scans ~20N per iteration; 2m^2 + 2mN per refinement pass)."""
     plan = 60 * (N + 1) + 400
     if workload in ("c2", "c4"):
         fixed = plan + 2 * (ncomp * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)

@@ -11,10 +11,10 @@
 // rows), 2N x 2N, symmetric.  The set is found by exchanging bounds (per iteration the bound whose multiplier has the
 // wrong sign by the most leaves, the bound the new point violates by the most enters) started from the previous
 // closed-loop step's set moved one stage ahead; when nothing is left to exchange the KKT conditions hold, i.e. U is
-// the unique minimiser.  The result is then certified
-// with H itself (Newton correction of the point on its set, computed from the Hessian, not from its inverse) and
-// refined through the same factorisation.  Whatever does not end that way within a few iterations (sets larger than
-// the capacity, a cycling iteration) is left to the interior point.
+// the unique minimiser.  The result is then refined through the same factorisation (what it misses its active bounds
+// by) and certified by the size of that correction; optionally the correction is the Newton step computed from H
+// itself (ASET_CERT_FROM_H).  Whatever does not end that way within a few iterations (sets larger than the capacity,
+// a cycling iteration) is left to the interior point.
 #pragma once
 #include <utility>
 #include "mpc_wave.hpp"
@@ -41,6 +41,12 @@ constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a
 #define ASET_DU_EARLY 1e-6
 #endif
 constexpr double ASET_DU_TOL = 1e-10;
+// what a point may miss its active bounds by (relative to the bound) without being refined
+constexpr double ASET_MISS_TOL = 1e-12;
+// 1: the certificate's correction is the Newton step computed from H itself instead of the refinement through the table
+#ifndef ASET_CERT_FROM_H
+#define ASET_CERT_FROM_H 0
+#endif
 // entries of a column of H (or of its inverse) requested at a time in the certificate: one memory round trip per chunk, two
 // registers per entry while it waits
 // rows of the table requested at a time when the inputs are updated (smallest size class / the others)
@@ -213,7 +219,7 @@ struct AsetResult {
     int au, ad;        // this lane's input / steering bound in the set: +1 upper, -1 lower, 0 none
     int iters;         // active-set iterations spent so far
     int flops;         // floating-point operations spent so far (the method's own count: LDL' m^3/3, two solves 2m^2,
-                       // the update of the inputs 2mN, scans ~20N per iteration; 4N^2 + 2m^2 + 2mN per certificate pass)
+                       // the update of the inputs 2mN, scans ~20N per iteration; 2m^2 + 2mN per refinement pass, 4N^2 more from H)
     int why;           // ASET_SOLVED, or handed on: GROW the set outgrew this size class, UNSETTLED the iteration did not
                        // settle within ASET_MAX_ITER, UNCERTIFIED the corrections of the certificate stayed too large
 };
@@ -338,14 +344,20 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     if (!converged) return out;
     out.why = ASET_UNCERTIFIED;
 
-    // Certificate from H itself: the Newton correction of the point on its active set, computed from the residual of
-    // H U + g + E' nu (the Hessian, not its cached inverse), through the factorisation at hand:
-    //   r = H (U - Uu) + E' nu,  z = inv(H) r,  w = inv(S) (E z - (E U - b)),  nu -= w,  U += -z + inv(H) E' w.
-    // The size of the correction is the error of the point it is applied to.
+    // Refinement and certificate.  What the point misses its active bounds by (the rounding of the factorisation and of
+    // the triangular solves, large where rows of the set are close to dependent) is put through the factorisation at
+    // hand once more:  w = inv(S) (-(E U - b)),  nu -= w,  U += inv(H) E' w;  the size of that correction is the error
+    // of the point it is applied to.  This trusts the table as the unconstrained steps trust the cached maps that
+    // U_unc comes from (both are written by one launch of k_condense_fixed from one factorisation of H).
+    // With ASET_CERT_FROM_H the correction is the full Newton step computed from H itself:
+    //   r = H (U - Uu) + E' nu,  z = inv(H) r,  w = inv(S) (E z - (E U - b)),  nu -= w,  U += -z + inv(H) E' w
+    // (two more passes over N x N matrices per solve, about a fifth of the solve's time, for an answer that differs
+    // from the 80-bit checker's by the same 1e-10 of the input bound either way).
     bool certified = false;
 #pragma unroll 1
     for (int pass = 0; pass < 3 && !certified; pass++) {
-        out.flops += 4 * N * N + 2 * m * m + 2 * m * N;
+        double z = 0.0;
+        if (ASET_CERT_FROM_H) {
         const double dU = valid ? U - Uu : 0.0;
         // (a column of H, then one of inv(H), in chunks of ASET_COL_CHUNK entries requested before the first is used)
         double hu0 = 0.0, hu1 = 0.0;
@@ -380,9 +392,17 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const double z = valid ? z0 + z1 : 0.0;
-        const double pz = dt * incl_prefix(z, lane);
+        z = valid ? z0 + z1 : 0.0;
+        }
+        const double pz = ASET_CERT_FROM_H ? dt * incl_prefix(z, lane) : 0.0;
         const double vdc = dt * incl_prefix(valid ? U : 0.0, lane);
+        if (!ASET_CERT_FROM_H) {
+            double miss = 0.0;
+            if (au != 0) miss = fabs(U - (au > 0 ? umax : -umax)) / umax;
+            if (ad != 0) miss = fmax(miss, in_run ? fabs(U - b_run) / umax : fabs(vdc - b_run) / dmax);
+            if (wave_max(miss) <= ASET_MISS_TOL) { certified = true; break; }      // at rounding level: nothing to refine
+        }
+        out.flops += (ASET_CERT_FROM_H ? 4 * N * N : 0) + 2 * m * m + 2 * m * N;
         // right-hand side E z - (E U - b): the correction also closes what the point misses its active bounds by
         if (au != 0) val_l[rank_u] = z - (U - (au > 0 ? umax : -umax));
         if (ad != 0) val_l[rank_d] = in_run ? z - (U - b_run) : pz - (vdc - b_run);
