@@ -56,7 +56,7 @@ extern "C" {
 
 #define MPC_QP_AUTO 0            /* active-set solve first where the fixed-model cache is on, interior point otherwise */
 #define MPC_QP_INTERIOR_POINT 1  /* interior point for every constrained solve */
-#define MPC_QP_ACTIVE_SET 2      /* as AUTO, and the active-set solve also inside mpc_ofl_closed_loop_run */
+#define MPC_QP_ACTIVE_SET 2      /* the same as AUTO */
 
 /* Controller definition; what the reference's constructors derive from parameters_*.yaml
  * (LMPC2.py:14-96, LPVMPC.py:10-92, OFLMPC2.py:16-100). */
@@ -95,12 +95,11 @@ typedef struct mpc_config {
     int qp_method;       /* how a solve whose unconstrained minimiser violates a bound is finished.  MPC_QP_AUTO: with the
                           * fixed-model cache on (mpc_condense_fixed) the active bounds are found by a primal-dual active-set
                           * iteration started from the previous closed-loop step's set and the multipliers come from a small
-                          * system built from the cached inv(H); the result is certified by its KKT residual, and whatever
-                          * does not end that way (large or cycling sets) goes to the interior point.  Both give the unique
-                          * minimiser (they agree to the solver tolerances, not bit for bit).
-                          * MPC_QP_INTERIOR_POINT: interior point only.  MPC_QP_ACTIVE_SET: as AUTO, and also inside
-                          * mpc_ofl_closed_loop_run, which under AUTO keeps the interior point (its noisy estimates make the
-                          * active sets jump from step to step; without noise the method is the faster one there too) */
+                          * system built from the cached inv(H); the result is refined through that system and certified
+                          * by the size of the refinement, and whatever does not end that way (large or cycling sets) goes
+                          * to the interior point.  Both give the unique minimiser (they agree to the solver tolerances,
+                          * not bit for bit).  MPC_QP_INTERIOR_POINT: interior point only.  MPC_QP_ACTIVE_SET: the same as
+                          * AUTO (kept for callers written when mpc_ofl_closed_loop_run needed it to use the method) */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

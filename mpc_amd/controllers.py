@@ -114,8 +114,7 @@ class _CondensedMpc:
         # kernel, from 2048 scenarios up), wave otherwise
         self._layout = _lib.LAYOUT[solver_layout]
         # "auto": constrained solves of the fixed-model path go through the active-set method first (interior point where
-        # it does not end at the minimiser); "interior_point": interior point only; "active_set": as "auto", and also inside
-        # the fused output-feedback loop (which keeps the interior point under "auto")
+        # it does not end at the minimiser); "interior_point": interior point only; "active_set": the same as "auto"
         self._qp_method = _lib.QP_METHOD[qp_method]
         if terminal_set is not None and solver_layout == "auto":
             self._layout = _lib.LAYOUT["lane"]          # general terminal rows are handled by the stage-wise solver

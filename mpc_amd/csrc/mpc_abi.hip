@@ -427,12 +427,11 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    // With MPC_QP_AUTO the output-feedback loop keeps the interior point: on noisy estimates (the workload this entry point
-    // exists for) the active sets are large and jump from step to step, a third of the attempts are handed on, and the
-    // method is no faster (measured on 8192 scenarios x 300 steps with the EKF's measurement noise: 7.9 M scenario-steps/s
-    // without it, 7.5 M with it).  Without noise the sets move one stage per step and it is 2.3 times faster
-    // (256 scenarios x 80 steps: 9.1 ms against 20.5 ms): MPC_QP_ACTIVE_SET asks for it here too.
-    if (h->cfg.qp_method != MPC_QP_ACTIVE_SET) a.sh_T = nullptr;
+    // The active-set solve runs here too (MPC_QP_AUTO): on noisy estimates the active sets are large and jump from step to
+    // step, a third of the attempts are handed on and the gain is small (8192 scenarios x 300 steps with the EKF's
+    // measurement noise: 8.3 M scenario-steps/s against 7.9 M with the interior point alone, with the kernel's smaller
+    // iteration cap for this loop); without noise the sets move one stage per step and it is 2.3 times faster
+    // (256 scenarios x 80 steps: 9.1 ms against 20.5 ms).
     h->last_B = B;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;

@@ -29,11 +29,9 @@ typedef __attribute__((address_space(3))) int aset_lint;
 
 // iteration caps (counted over the whole solve): an iteration of the largest size class costs about as much as one of
 // the interior point, so a set of that size that has not settled after a few exchanges is handed on
-constexpr int ASET_MAX_ITER = 10;
-#ifndef ASET_CAP_LARGE
-#define ASET_CAP_LARGE 6
-#endif
-__device__ __forceinline__ constexpr int aset_iter_cap(int MM) { return MM <= 32 ? 10 : ASET_CAP_LARGE; }
+constexpr int ASET_MAX_ITER = 10;       // size classes up to 32
+constexpr int ASET_CAP_LARGE = 6;       // the larger classes; the caller passes its own (`cap_large`): the output-feedback
+constexpr int ASET_CAP_LARGE_NOISY = 4; // loop, whose sets jump with the estimate's noise, hands on earlier (measured)
 constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a previous set starts from
 // sizes of the certificate's corrections relative to the input bound: a first correction below EARLY is taken as final
 // (what is left after it is smaller by the accuracy of the cached inverse), a later one has to come out below TOL
@@ -234,7 +232,7 @@ struct AsetResult {
 template <int N, int MM>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
-                                                double *rec, int au, int ad, int it0, int fl0, double *lds)
+                                                double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large)
 {
     constexpr unsigned LD = 2 * N;                       // row length of T
     const bool valid = lane < N, validd = lane < N - 1;
@@ -252,8 +250,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0, tm = 0.0, b_run = 0.0;
     int my_cid = 0, m = 0, rank_u = 0, rank_d = 0;
     bool converged = false, in_run = false;
+    const int it_cap = MM <= 32 ? ASET_MAX_ITER : cap_large;
 #pragma unroll 1
-    for (int it = it0; it < aset_iter_cap(MM); it++) {
+    for (int it = it0; it < it_cap; it++) {
         // a steering bound whose predecessor stage is active on the same side enters as "this input = the step between
         // the two bounds" (0 unless the bound was widened): see aset_steer_multiplier.  Such an input cannot sit at its
         // rate bound as well (the step between two steering bounds is never the full rate): that bound leaves the set.
@@ -451,8 +450,8 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 #define ASET_CLASS_LINKAGE __forceinline__
 #endif
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
-                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds
-#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds
+                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large
+#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large
 template <int N, int MM, int TAG>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_small(MPC_ASET_ARGS)
 {
@@ -482,7 +481,7 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_full(MPC_ASET_ARGS)
 template <int N, int TAG>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
-                                                       double *rec, bool rec_valid, double *lds)
+                                                       double *rec, bool rec_valid, double *lds, int cap_large)
 {
     constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3);
     const bool valid = lane < N, validd = lane < N - 1;
@@ -504,18 +503,18 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
     int m = __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0));
     if (!rec_valid && m > ASET_COLD_MAX) return r;       // a large violated set says little about the active one
-    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
+    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
     if (C1 > C0 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
+        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
+        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
     }
     if (C3 > C2 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds);
+        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
     }
     return r;
 }

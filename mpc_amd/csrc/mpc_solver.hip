@@ -136,7 +136,7 @@ struct ConstrainedResult {
 template <int N, int TAG>
 static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(IpmParams prm, int lane, const double *Hm, const double *T,
                                                                    double Uu, double vdu, double up_d, double lo_d, double *lds,
-                                                                   int *as_o)
+                                                                   int *as_o, int as_cap_large)
 {
     ConstrainedResult out = {0.0, 0.0, 0.0, 0, 0, 0, false};
     // Back-off: a scenario whose active-set solves keep being handed on (the output-feedback loop on its way to the step:
@@ -150,7 +150,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
         if (lane == 0) bo[0] = (double)(wait - 1);
     } else if (T) {
         const AsetResult r = active_set_solve<N, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
-                                                      prm.warm_mode != 0, lds);
+                                                      prm.warm_mode != 0, lds, as_cap_large);
         out.work = r.iters;
         // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
         // registers of the step loop they would crowd the unconstrained steps.  (Atomics without a return value: nothing
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 // (s_ref is dead once U_unc is formed: the solvers borrow it)
                 const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
                 const ConstrainedResult r = solve_constrained<N, GENERAL ? 1 : 2>(prm, lane, Hm, a.sh_T, Uu, vd, up_d, lo_d, s_ref,
-                                                                                  a.as_out ? a.as_out + 6 * (size_t)s : nullptr);
+                                                                                  a.as_out ? a.as_out + 6 * (size_t)s : nullptr,
+                                                                                  a.mode == MODE_OFL ? ASET_CAP_LARGE_NOISY : ASET_CAP_LARGE);
                 U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
                 solved_warm = (warm_rec != nullptr) && r.warm_valid;
                 work_tot += r.work;

@@ -73,9 +73,8 @@ def test_output_feedback_loop_methods(orc64):
     """The fused output-feedback loop (simulator.py:206-281).  On the way to the step every input of its problems is fixed
     by a bound (full rate until the steering angle saturates, then the angle bound to the end of the horizon: as many
     active bounds as inputs); a run of active steering bounds enters the multiplier system as unit rows, which keeps that
-    system as well conditioned as inv(H).  qp_method "auto" keeps the interior point in this loop (its measurement noise
-    makes the sets jump), "active_set" asks for the active-set solve: without noise nearly every solve ends there, and
-    both follow the checker's loop."""
+    system as well conditioned as inv(H).  Without noise nearly every solve ends in the active-set method ("auto", and
+    "active_set", which is the same thing), "interior_point" switches it off, and all follow the checker's loop."""
     import torch
     from oracle import oracle as O
     from mpc_amd.batched import StepOFLBatch
@@ -97,9 +96,9 @@ def test_output_feedback_loop_methods(orc64):
         out[method] = (xs.cpu().numpy(), us.cpu().numpy(), sim.ocp.stats())
         assert (np.abs(out[method][1] - u_ref) <= 10 * _tol(u_ref, cfg[10])).all(), (method, np.abs(out[method][1] - u_ref).max())
         assert np.abs(out[method][0] - x_ref).max() <= 1e-7, method
-    assert np.array_equal(out["auto"][1], out["interior_point"][1])              # the same arithmetic
+    assert np.array_equal(out["auto"][1], out["active_set"][1])                  # the same arithmetic
     sa = out["active_set"][2]
-    assert out["auto"][2]["n_active_set_solves"] == 0 and sa["n_active_set_solves"] >= 0.8 * sa["n_constrained"] > 0
+    assert out["interior_point"][2]["n_active_set_solves"] == 0 and sa["n_active_set_solves"] >= 0.8 * sa["n_constrained"] > 0
     assert sa["sum_iterations"] < 0.25 * out["interior_point"][2]["sum_iterations"]
 
 
