@@ -228,8 +228,11 @@ def build_workload(name: str, B: int, rank: int, dev, steps_total: int, qp_metho
 
 
 SUM_KEYS = ("scenario_steps", "ipm_iterations", "constrained_solves", "status_nonzero", "sqp_iterations", "sum_abs_u0",
-            "active_set_solves", "active_set_iterations", "active_set_handed_on", "active_set_flops")
-MAX_KEYS = ("elapsed_s", "max_abs_u0", "max_complementarity", "max_residual")
+            "active_set_solves", "active_set_iterations", "active_set_handed_on", "active_set_flops",
+            # closed-loop statistics of the timed region (mpc_get_stats slots 16-19, 23)
+            "stage_cost", "lateral_error_sq", "heading_pair_violation", "input_sq", "closed_loop_steps")
+MAX_KEYS = ("elapsed_s", "max_abs_u0", "max_complementarity", "max_residual",
+            "max_bound_violation", "max_heading_pair_violation", "max_predicted_heading_pair_violation")
 
 
 def reduce_statistics(sums: dict, maxima: dict, device=None) -> tuple[dict, dict]:
@@ -270,8 +273,12 @@ def dry_run(args, rank: int, world: int) -> None:
     sums = {"scenario_steps": (hi - lo) * args.steps, "ipm_iterations": 2.0 * (hi - lo) * args.steps,
             "constrained_solves": 0.5 * (hi - lo) * args.steps, "status_nonzero": 0, "sqp_iterations": 0, "sum_abs_u0": 0.1 * (hi - lo),
             "active_set_solves": 0.4 * (hi - lo) * args.steps, "active_set_iterations": 1.0 * (hi - lo) * args.steps,
-            "active_set_handed_on": 0.1 * (hi - lo) * args.steps, "active_set_flops": 1e4 * (hi - lo) * args.steps}
-    maxima = {"elapsed_s": 1.0 + rank, "max_abs_u0": 0.1 * (rank + 1), "max_complementarity": 1e-16, "max_residual": 1e-13}
+            "active_set_handed_on": 0.1 * (hi - lo) * args.steps, "active_set_flops": 1e4 * (hi - lo) * args.steps,
+            "stage_cost": 3.0 * (hi - lo) * args.steps, "lateral_error_sq": 0.01 * (hi - lo) * args.steps,
+            "heading_pair_violation": 1e-15 * (hi - lo) * args.steps, "input_sq": 0.04 * (hi - lo) * args.steps,
+            "closed_loop_steps": (hi - lo) * args.steps}
+    maxima = {"elapsed_s": 1.0 + rank, "max_abs_u0": 0.1 * (rank + 1), "max_complementarity": 1e-16, "max_residual": 1e-13,
+              "max_bound_violation": 0.0, "max_heading_pair_violation": 1e-14 * (rank + 1), "max_predicted_heading_pair_violation": 0.0}
     sums, maxima = reduce_statistics(sums, maxima)
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": sums["scenario_steps"] / maxima["elapsed_s"], "unit": "scenario-steps/s",
@@ -385,9 +392,15 @@ def main() -> None:
             # the active-set counters describe the last launch: the timed region in the fused mode, its last step otherwise
             "active_set_solves": float(st16["n_active_set_solves"]), "active_set_iterations": float(st16["sum_active_set_iterations"]),
             "active_set_handed_on": float(st16["n_active_set_too_large"] + st16["n_active_set_unsettled"]),
-            "active_set_flops": float(st16["sum_active_set_flops"])}
+            "active_set_flops": float(st16["sum_active_set_flops"]),
+            # closed-loop statistics: the last launch too (every step of the timed region in the fused mode)
+            "stage_cost": st16["sum_stage_cost"], "lateral_error_sq": st16["sum_lateral_error_sq"],
+            "heading_pair_violation": st16["sum_heading_pair_violation"], "input_sq": st16["sum_input_sq"],
+            "closed_loop_steps": st16["closed_loop_steps"]}
     maxima = {"elapsed_s": elapsed, "max_abs_u0": float(st16["max_abs_u0"]), "max_complementarity": float(st16["max_complementarity"]),
-              "max_residual": float(st16["max_residual"])}
+              "max_residual": float(st16["max_residual"]), "max_bound_violation": st16["max_bound_violation"],
+              "max_heading_pair_violation": st16["max_heading_pair_violation"],
+              "max_predicted_heading_pair_violation": st16["max_predicted_heading_pair_violation"]}
     sums, maxima = reduce_statistics(sums, maxima, dev)       # RCCL: the only collective of the path
     elapsed = maxima["elapsed_s"]
     kernel_ms = np.array([a.elapsed_time(b) for a, b in ev])
@@ -453,6 +466,15 @@ def main() -> None:
                        "max_residual": maxima["max_residual"],
                        "transient_scenario_steps_per_s": (B * world * args.warmup / t_warm) if args.warmup else None,
                        "steady_state": steady},
+            # cost and constraint-violation statistics of the timed steps, all-reduced over the ranks (sums add, maxima max)
+            "closed_loop": {"scenario_steps_covered": sums["closed_loop_steps"],
+                            "mean_stage_cost_per_step": sums["stage_cost"] / max(1.0, sums["closed_loop_steps"]),
+                            "rms_lateral_error_m": float(np.sqrt(sums["lateral_error_sq"] / max(1.0, sums["closed_loop_steps"]))),
+                            "rms_input_rad_s": float(np.sqrt(sums["input_sq"] / max(1.0, sums["closed_loop_steps"]))),
+                            "mean_heading_pair_violation": sums["heading_pair_violation"] / max(1.0, sums["closed_loop_steps"]),
+                            "max_heading_pair_violation": maxima["max_heading_pair_violation"],
+                            "max_predicted_heading_pair_violation": maxima["max_predicted_heading_pair_violation"],
+                            "max_bound_violation": maxima["max_bound_violation"]},
         }
         fp64 = {"achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_TFLOPS,
                 "algorithmic_flops_per_scenario_step": flops}

@@ -128,7 +128,8 @@ int mpc_set_cost_weights(mpc_handle *h, const double *cost_per_scenario);
  * set: then the caller promises that every scenario runs at vx, a leaner kernel without the per-scenario path is
  * launched, and a scenario that breaks the promise is not solved but reported with status 3.  vx = NaN switches
  * the cache off.  Horizons without a register-resident kernel (anything but 10, 20, 30, 40, 50, 64) have no cache:
- * the call succeeds and changes nothing, and those horizons keep condensing per scenario.  Plays the role of the one-time QP data set-up inside AcadosOcpSolver(ocp) (LMPC2.py:94). */
+ * the call succeeds and changes nothing, and those horizons keep condensing per scenario.  With the table it waits for
+ * the set-up kernel (the table is checked against H: mpc_get_stats slots 14, 15); without it the call is asynchronous.  Plays the role of the one-time QP data set-up inside AcadosOcpSolver(ocp) (LMPC2.py:94). */
 int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive);
 
 /* optimize(): the yref/p set loop + solve_for_x0 + x/u get loop of LMPC2.py:296-347,
@@ -274,16 +275,33 @@ int mpc_set_terminal_set(mpc_handle *h, int m, const double *C_host);
  * reference never resets it); for callers that reuse a handle for new scenarios. */
 int mpc_reset_warm_start(mpc_handle *h, void *stream);
 
-/* Sum / max statistics over the scenarios of the last mpc_solve_only / mpc_closed_loop_step call,
- * copied to a host array of 16 doubles after synchronising the stream:
+/* Sum / max statistics over the scenarios of the last mpc_solve_only / closed-loop call,
+ * copied to a host array of MPC_STATS_LEN doubles after synchronising the stream:
  *   [0] scenarios, [1] sum iterations, [2] count status != 0, [3] count constrained solves,
  *   [4] sum |u0|, [5] max |u0|, [6] max final complementarity, [7] max final residual, [8] sum of SQP iterations (MPC_KIND_NL),
  *   [9] constrained solves finished by the active-set method, [10] sum of its iterations, [11] solves it handed to the
  *   interior point because the active set outgrew its capacity or was rank-deficient, [12] because its iteration did not
  *   settle or its result did not certify, [13] floating-point operations of the active-set solves (the method's own
- *   count); rest reserved.
- *   [1] counts interior-point iterations only. */
-int mpc_get_stats(mpc_handle *h, void *stream, double *host16);
+ *   count); [14] largest entry of |H inv(H) - I| of the fixed-model cache's table (checked when mpc_condense_fixed builds
+ *   it), [15] 1 when that exceeded 1e-9 and the active-set method was therefore left off for this cache (every
+ *   constrained solve then goes to the interior point, which works from H itself), else 0.
+ *   [1] counts interior-point iterations only.
+ * Closed-loop statistics, over every scenario and every step of the last mpc_closed_loop_step / mpc_closed_loop_run /
+ * mpc_ofl_closed_loop_run call (zero after mpc_solve_only): what the reference's experiments judge a run by
+ * (skidpad_simulator.py:134-135 prints the heading pair's violation per step; plot_generator.py:1057-1072 measures the
+ * tracking of the lateral reference; the cost is the controller's own LINEAR_LS stage cost, LMPC2.py:220-253):
+ *   [16] sum of the stage cost at the start of the horizon with the applied input, dt * 1/2 |[x0; u0] - yref_0|^2_W
+ *        (per-scenario weights where mpc_set_cost_weights gave them; the NL controller's W for MPC_KIND_NL),
+ *   [17] sum of the squared lateral offset of the first reference point in the car frame (tracking error),
+ *   [18] sum and [21] max of | |(cos, sin)| - 1 | of the plant's heading pair after each step,
+ *   [19] sum of the squared applied inputs,
+ *   [20] max excess of |u0| over the rate bound or of the plant's steering angle over its bound (0: never exceeded),
+ *   [22] max of | |(cos, sin)| - 1 | over the predicted trajectories (MPC_KIND_NL, where the pair is a model state; the
+ *        linear controllers rebuild the pair from the angle: 0),
+ *   [23] scenario-steps counted; rest reserved.
+ * In a multi-GPU run [0]-[4], [8]-[13], [16]-[19], [23] add and [5]-[7], [20]-[22] take the maximum over the ranks. */
+#define MPC_STATS_LEN 32
+int mpc_get_stats(mpc_handle *h, void *stream, double *host_out);
 
 #ifdef __cplusplus
 }

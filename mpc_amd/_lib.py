@@ -28,6 +28,16 @@ class MpcConfig(C.Structure):
     ]
 
 
+# slots of mpc_get_stats (include/mpc_amd.h); the *_max slots combine by maximum over GPUs, the others add
+STATS_LEN = 32
+STATS_SLOTS = {0: "scenarios", 1: "sum_iterations", 2: "n_status_nonzero", 3: "n_constrained", 4: "sum_abs_u0", 5: "max_abs_u0",
+               6: "max_complementarity", 7: "max_residual", 8: "sum_sqp_iterations", 9: "n_active_set_solves",
+               10: "sum_active_set_iterations", 11: "n_active_set_too_large", 12: "n_active_set_unsettled",
+               13: "sum_active_set_flops", 14: "max_table_residual", 15: "n_active_set_switched_off", 16: "sum_stage_cost", 17: "sum_lateral_error_sq", 18: "sum_heading_pair_violation",
+               19: "sum_input_sq", 20: "max_bound_violation", 21: "max_heading_pair_violation",
+               22: "max_predicted_heading_pair_violation", 23: "closed_loop_steps"}
+STATS_MAX_SLOTS = (5, 6, 7, 14, 20, 21, 22)
+
 _vp = C.c_void_p
 _dp = C.POINTER(C.c_double)
 _SIGS = {

@@ -322,13 +322,12 @@ class _CondensedMpc:
         _lib.check(rc, self.solver.h, "mpc_reset_warm_start")
 
     def stats(self) -> dict:
-        out = np.zeros(16)
+        """Sums and maxima over the scenarios of the last call (include/mpc_amd.h, mpc_get_stats).  The keys from
+        "sum_stage_cost" on are the closed-loop statistics of the last closed-loop run (zero after optimize())."""
+        out = np.zeros(_lib.STATS_LEN)
         rc = self.solver._lib.mpc_get_stats(self.solver.h, _dev.stream_ptr(self.device), _lib.hptr(out))
         _lib.check(rc, self.solver.h, "mpc_get_stats")
-        keys = ["scenarios", "sum_iterations", "n_status_nonzero", "n_constrained", "sum_abs_u0", "max_abs_u0",
-                "max_complementarity", "max_residual", "sum_sqp_iterations", "n_active_set_solves",
-                "sum_active_set_iterations", "n_active_set_too_large", "n_active_set_unsettled", "sum_active_set_flops"]
-        return dict(zip(keys, out[:14]))
+        return {k: float(out[i]) for i, k in _lib.STATS_SLOTS.items()}
 
 
 class LOcp(_CondensedMpc):

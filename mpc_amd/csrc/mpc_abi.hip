@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "mpc_kernels.h"
+#include "mpc_device.hpp"      // CL_STAT_W
 
 struct mpc_handle {
     mpc_config cfg;
@@ -25,9 +26,13 @@ struct mpc_handle {
     double *term_C = nullptr;    // optional terminal set rows [term_m][5] (lane layout)
     int term_m = 0;
     bool px_free = false;        // nothing weighs the longitudinal position (controller weights, or every row of cost_scen)
-    double *stats16 = nullptr;   // device result of the statistics reduction
+    double *stats_out = nullptr; // device result of the statistics reduction (MPC_STATS_LEN) and its per-workgroup partial vectors
+    double *cl_stat = nullptr;   // B * 8 closed-loop statistics of the last closed-loop call
+    bool cl_valid = false;       // the last call was a closed-loop call (cl_stat belongs to it)
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double *sh_T = nullptr;      // table of the active-set solve (part of the cache; NULL with qp_method = interior point)
+    double sh_T_resid = 0.0;     // largest entry of |H inv(H) - I| of that table (checked when it is built)
+    bool sh_T_ok = false;        // the table is accurate enough for the active-set solve to certify its points with
     int *as2 = nullptr;          // B * 6: active-set counters of the last call (SolveArgs::as_out)
     double sh_vx = 0.0;
     int sh_mask = 0;
@@ -37,6 +42,11 @@ struct mpc_handle {
 };
 
 static thread_local std::string g_create_err;
+
+// Largest entry of |H inv(H) - I| the cached table of the active-set solve may show.  A point the method returns is exact
+// on its active bounds and stationary up to the table's relative error times the distance from the unconstrained
+// minimiser (at most twice the input bound): 1e-9 keeps that four orders below the 1e-5 the inputs are held to.
+static const double ASET_TABLE_RESID_MAX = 1e-9;
 
 static int fail(mpc_handle *h, int code, const std::string &msg)
 {
@@ -158,7 +168,9 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     }
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&h->stats16, 16 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->stats_out, (size_t)(1 + mpc::STATS_BLOCKS) * MPC_STATS_LEN * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->cl_stat, B * mpc::CL_STAT_W * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(h->cl_stat, 0, B * mpc::CL_STAT_W * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->as2, B * 6 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->as2, 0, B * 6 * sizeof(int));
     if (e != hipSuccess) {
@@ -175,7 +187,7 @@ void mpc_destroy(mpc_handle *h)
     if (!h) return;
     DeviceScope scope(h->cfg.device);
     (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
-    (void)hipFree(h->stats16); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
+    (void)hipFree(h->stats_out); (void)hipFree(h->cl_stat); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T); (void)hipFree(h->as2);
     (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
     delete h;
@@ -267,7 +279,16 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
             return hip_fail(h, e, "mpc_condense_fixed: cache allocation");
         }
     }
-    HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, h->sh_T, (hipStream_t)stream));
+    // The active-set solve refines and certifies its points through the table alone; the table is therefore checked
+    // against H once, here (a set-up call: it waits for the kernel).  Beyond ASET_TABLE_RESID_MAX the method stays off
+    // for this cache and every constrained solve goes to the interior point, which works from H itself.
+    HIP_TRY(h, mpc::launch_condense_fixed(h->dev, vx, h->sh_H, h->sh_Kref, h->sh_Kx, h->sh_T, h->stats_out, (hipStream_t)stream));
+    h->sh_T_resid = 0.0; h->sh_T_ok = false;
+    if (h->sh_T) {
+        HIP_TRY(h, hipMemcpyAsync(&h->sh_T_resid, h->stats_out, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+        h->sh_T_ok = h->sh_T_resid <= ASET_TABLE_RESID_MAX;      // (a NaN fails the test)
+    }
     h->sh_vx = vx;
     h->sh_mask = 0;
     for (int c = 0; c < 3; c++) {
@@ -284,7 +305,7 @@ static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
 {
     if (h->sh_on && !h->mp_scen && !h->cost_scen) {
         a.sh_H = h->sh_H; a.sh_Kref = h->sh_Kref; a.sh_Kx = h->sh_Kx; a.sh_vx = h->sh_vx; a.sh_mask = h->sh_mask; a.sh_exclusive = h->sh_exclusive ? 1 : 0;
-        a.sh_T = h->sh_T;
+        a.sh_T = h->sh_T_ok ? h->sh_T : nullptr;
     }
     a.as_out = h->as2;
 }
@@ -360,7 +381,7 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
     a.stat_out = h->stat;
     attach_cache(h, a);
-    h->last_B = B;
+    h->last_B = B; h->cl_valid = false;
     HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
@@ -400,9 +421,9 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
-    a.stat_out = h->stat;
+    a.stat_out = h->stat; a.cl_stat = h->cl_stat;
     attach_cache(h, a);
-    h->last_B = B;
+    h->last_B = B; h->cl_valid = true;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
@@ -425,14 +446,14 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
-    a.stat_out = h->stat;
+    a.stat_out = h->stat; a.cl_stat = h->cl_stat;
     attach_cache(h, a);
     // The active-set solve runs here too (MPC_QP_AUTO): on noisy estimates the active sets are large and jump from step to
     // step, a third of the attempts are handed on and the gain is small (8192 scenarios x 300 steps with the EKF's
     // measurement noise: 8.3 M scenario-steps/s against 7.9 M with the interior point alone, with the kernel's smaller
     // iteration cap for this loop); without noise the sets move one stage per step and it is 2.3 times faster
     // (256 scenarios x 80 steps: 9.1 ms against 20.5 ms).
-    h->last_B = B;
+    h->last_B = B; h->cl_valid = true;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
     return MPC_OK;
 }
@@ -501,14 +522,17 @@ int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const dou
     return MPC_OK;
 }
 
-int mpc_get_stats(mpc_handle *h, void *stream, double *host16)
+int mpc_get_stats(mpc_handle *h, void *stream, double *host_out)
 {
-    if (!h || !host16) return MPC_EINVAL;
+    if (!h || !host_out) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
     ON_HANDLE_DEVICE(h);
-    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->as2, h->stats16));
-    HIP_TRY(h, hipMemcpyAsync(host16, h->stats16, 16 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->as2,
+                                 h->cl_valid ? h->cl_stat : nullptr, h->stats_out + MPC_STATS_LEN, h->stats_out));
+    HIP_TRY(h, hipMemcpyAsync(host_out, h->stats_out, MPC_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    host_out[14] = h->sh_on && h->sh_T ? h->sh_T_resid : 0.0;
+    host_out[15] = h->sh_on && h->sh_T && !h->sh_T_ok ? 1.0 : 0.0;
     return MPC_OK;
 }
 

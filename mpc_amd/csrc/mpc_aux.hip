@@ -503,36 +503,61 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
 }
 
 // ------------------------------------------------------------------------------------------ statistics
-// Single-block reduction of the per-scenario solver records into 16 doubles (sums and maxima).
-__global__ __launch_bounds__(256) void k_stats(int B, const double *stat, const int *iters, const int *status,
-                                               const int *sqp, const int *as2, double *out16)
+// Reduction of the per-scenario records into MPC_STATS_LEN doubles (sums and maxima; the slots are listed at
+// mpc_get_stats in mpc_amd.h).  Two launches: up to STATS_BLOCKS workgroups write a partial vector each, one workgroup
+// combines them in a fixed order, so the sums do not depend on the timing of atomics.
+constexpr int ST_N = MPC_STATS_LEN;
+__device__ __forceinline__ bool stat_is_max(int c) { return (c >= 5 && c <= 7) || (c >= 20 && c <= 22); }
+
+__global__ __launch_bounds__(256) void k_stats_partial(int B, const double *stat, const int *iters, const int *status,
+                                                        const int *sqp, const int *as2, const double *cl, double *part)
 {
-    __shared__ double sh[14][256];
-    double acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = threadIdx.x; s < B; s += 256) {
+    __shared__ double sh[ST_N][256 + 1];
+    double acc[ST_N];
+#pragma unroll
+    for (int c = 0; c < ST_N; c++) acc[c] = 0.0;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < B; s += gridDim.x * 256) {
         const double *q = stat + 4 * (size_t)s;
         acc[0] += 1.0; acc[1] += iters[s]; acc[2] += (status[s] != 0); acc[3] += q[2]; acc[4] += q[3];
         acc[5] = fmax(acc[5], q[3]);
         if (q[2] != 0.0) { acc[6] = fmax(acc[6], q[0]); acc[7] = fmax(acc[7], q[1]); }
         if (sqp) acc[8] += sqp[s];
         if (as2) { acc[9] += as2[6 * s]; acc[10] += as2[6 * s + 1]; acc[11] += as2[6 * s + 2]; acc[12] += as2[6 * s + 3]; acc[13] += 64.0 * as2[6 * s + 4]; }
+        if (cl) {
+            const double *r = cl + CL_STAT_W * (size_t)s;
+            acc[16] += r[CL_COST]; acc[17] += r[CL_EY2]; acc[18] += r[CL_TRIG_SUM]; acc[19] += r[CL_U2];
+            acc[20] = fmax(acc[20], r[CL_BOUND_MAX]); acc[21] = fmax(acc[21], r[CL_TRIG_MAX]); acc[22] = fmax(acc[22], r[CL_PRED_TRIG_MAX]);
+            acc[23] += r[CL_STEPS];
+        }
     }
-    for (int c = 0; c < 14; c++) sh[c][threadIdx.x] = acc[c];
+#pragma unroll
+    for (int c = 0; c < ST_N; c++) sh[c][threadIdx.x] = acc[c];
     __syncthreads();
     for (int w = 128; w; w >>= 1) {
         if ((int)threadIdx.x < w)
-            for (int c = 0; c < 14; c++)
-                sh[c][threadIdx.x] = (c < 5 || c >= 8) ? sh[c][threadIdx.x] + sh[c][threadIdx.x + w]
-                                             : fmax(sh[c][threadIdx.x], sh[c][threadIdx.x + w]);
+            for (int c = 0; c < ST_N; c++)
+                sh[c][threadIdx.x] = stat_is_max(c) ? fmax(sh[c][threadIdx.x], sh[c][threadIdx.x + w]) : sh[c][threadIdx.x] + sh[c][threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x < 16) out16[threadIdx.x] = threadIdx.x < 14 ? sh[threadIdx.x][0] : 0.0;
+    if (threadIdx.x < ST_N) part[blockIdx.x * ST_N + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(64) void k_stats_final(int nblocks, const double *part, double *out)
+{
+    const int c = threadIdx.x;
+    if (c >= ST_N) return;
+    double v = 0.0;
+    for (int b = 0; b < nblocks; b++) v = stat_is_max(c) ? fmax(v, part[b * ST_N + c]) : v + part[b * ST_N + c];
+    out[c] = v;
 }
 
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
-                        const int *as2, double *out16)
+                        const int *as2, const double *cl_stat, double *part, double *out)
 {
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, B, stat, iters, status, sqp, as2, out16);
+    int nblocks = (B + 255) / 256;
+    if (nblocks > STATS_BLOCKS) nblocks = STATS_BLOCKS;
+    hipLaunchKernelGGL(k_stats_partial, dim3(nblocks), dim3(256), 0, st, B, stat, iters, status, sqp, as2, cl_stat, part);
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, nblocks, part, out);
     return hipGetLastError();
 }
 

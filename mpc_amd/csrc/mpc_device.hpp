@@ -169,6 +169,53 @@ __device__ __forceinline__ void plant_rk4(double *x, double u, double dt, const 
     plant_rk4_c<NX>(x, u, dt, plant_coef(mp, x[4]));
 }
 
+// ---------------------------------------------------------------- closed-loop statistics
+// What a batch of closed loops is judged by, per scenario, over the steps of one entry-point call (the kernels keep the
+// eight values on chip and write them once; mpc_get_stats reduces them over the scenarios):
+//   CL_COST      sum of the controller's own stage cost at the start of the horizon with the input that was applied,
+//                dt * 1/2 |[x0; u0] - yref_0|^2_W (LMPC2.py:220-253 with acados' scaling by the time step; x0 is the
+//                car-frame start state, yref_0 the first reference point)
+//   CL_EY2       sum of the squared lateral offset of the first reference point in the car frame (the tracking error)
+//   CL_U2        sum of the squared applied input
+//   CL_TRIG_SUM / CL_TRIG_MAX   | |(cos, sin)| - 1 | of the plant's heading pair after the step (the plant does not
+//                renormalise it; skidpad_simulator.py:134 prints the same quantity for the predicted trajectory)
+//   CL_PRED_TRIG_MAX   the same over the predicted trajectory, where the pair is a state of the model (NL controller;
+//                the linear controllers rebuild the pair from the angle, so it lies on the unit circle to rounding)
+//   CL_BOUND_MAX  largest excess of |u0| over the rate bound or of the plant's steering angle over its bound (0: none)
+//   CL_STEPS     steps counted
+constexpr int CL_STAT_W = 8;
+enum { CL_COST = 0, CL_EY2 = 1, CL_TRIG_SUM = 2, CL_U2 = 3, CL_BOUND_MAX = 4, CL_TRIG_MAX = 5, CL_PRED_TRIG_MAX = 6, CL_STEPS = 7 };
+
+// The part known before the solve: the state and reference terms of the stage cost (w: diag of W, 6 state weights then
+// the input's) and the tracking error.  r0x, r0y, r0s: first reference point (x, y, sin psi); x0 = (0, 0, 0, vy, r, delta).
+__device__ __forceinline__ void cl_before_solve(double *acc, double dt, const double *w, double r0x, double r0y, double r0s,
+                                                double vy, double r, double delta)
+{
+    acc[CL_COST] += 0.5 * dt * (w[0] * r0x * r0x + w[1] * r0y * r0y + w[2] * r0s * r0s + w[3] * vy * vy + w[4] * r * r + w[5] * delta * delta);
+    acc[CL_EY2] += r0y * r0y;
+}
+
+// The part known after the plant step: wu = the input's weight, (hc, hs, steer) = the plant's heading pair and steering
+// angle after the step.
+__device__ __forceinline__ void cl_after_step(double *acc, double dt, double wu, double u0, double hc, double hs, double steer,
+                                              double umax, double dmax)
+{
+    const double tv = fabs(sqrt(hc * hc + hs * hs) - 1.0);
+    acc[CL_COST] += 0.5 * dt * wu * u0 * u0;
+    acc[CL_U2] += u0 * u0;
+    acc[CL_TRIG_SUM] += tv;
+    acc[CL_TRIG_MAX] = fmax(acc[CL_TRIG_MAX], tv);
+    acc[CL_BOUND_MAX] = fmax(acc[CL_BOUND_MAX], fmax(fabs(u0) - umax, fabs(steer) - dmax));
+    acc[CL_STEPS] += 1.0;
+}
+
+// start of a launch: zeros, or what the previous launch of a chain left
+__device__ __forceinline__ void cl_load(double *acc, const double *rec, bool accumulate)
+{
+#pragma unroll
+    for (int i = 0; i < CL_STAT_W; i++) acc[i] = accumulate ? rec[i] : 0.0;
+}
+
 // ---------------------------------------------------------------- EKF linearisation
 // Off-diagonal and non-unit entries of F = I + dt*A of Dynamics.jacobian_forward_euler (continuous_dynamics.py:167-210),
 // including its log(vx) terms, the positive tf22dr and the 1/m side-force column (:151-165) the estimator depends on.

@@ -335,6 +335,11 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     constexpr int WS = 2 * WAVE;
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WS] == 1.0;
+    // closed-loop statistics of the scenario (every lane carries the same eight values)
+    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
+    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;
+    double cl[CL_STAT_W] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cl_on) cl_load(cl, a.cl_stat + CL_STAT_W * (size_t)s, a.accumulate != 0);
 
 #pragma unroll 1
     for (int t = 0; t < nsteps; t++) {
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             }
         }
         wave_sync();
+        if (cl_on) cl_before_solve(cl, dt, w_cl, s_ref[0], s_ref[N + 1], s_ref[2 * (N + 1)], xh3, xh4, xh5);
 
         // ------------------------------------------------------------ 2. per-stage model
         const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;
@@ -815,6 +821,7 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             const double oldx = plant[0];
             plant_rk4_c<10>(plant, u0, dt, pc);
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
+            if (cl_on) cl_after_step(cl, dt, w_cl[6], u0, plant[2], plant[3], plant[7], umax, dmax);
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {
                 double val = plant[0];
@@ -863,6 +870,10 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         if (a.stat_out) {
             double *so = a.stat_out + 4 * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
+        }
+        if (cl_on) {
+#pragma unroll
+            for (int i = 0; i < CL_STAT_W; i++) a.cl_stat[CL_STAT_W * (size_t)s + i] = cl[i];
         }
     }
 }

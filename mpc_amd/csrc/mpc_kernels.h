@@ -49,6 +49,7 @@ struct SolveArgs {
     int *status_own, *iters_own;                          // the handle's own copies (always written; mpc_get_stats reads them)
     int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)
     double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
+    double *cl_stat;                                      // closed-loop modes: B * CL_STAT_W statistics of the run (mpc_device.hpp), or NULL
     // A long closed-loop run is issued as a chain of launches: `order` (a permutation of 0..B-1, or NULL) maps the
     // wave index to the scenario it advances, so that scenarios that needed many solver iterations in the previous
     // launch start first and share a workgroup; work_out [B] receives this launch's iterations per scenario; with
@@ -100,7 +101,8 @@ hipError_t launch_mpc_any(const DevCfg &cfg, const SolveArgs &a, hipStream_t st)
 // lanes_workspace_doubles(N, Bcap) doubles laid out for a capacity of Bcap scenarios, and keeps the warm-start record between calls
 hipError_t launch_mpc_lanes(const DevCfg &cfg, const SolveArgs &a, double *ws, size_t Bcap, hipStream_t st);
 size_t lanes_workspace_doubles(int N, int B, int term_m);
-hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st);
+// resid (one double, device; may be NULL): receives the largest entry of |H inv(H) - I| of the table T
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, double *resid, hipStream_t st);
 bool horizon_supported(int N);    // 2..MPC_MAX_HORIZON
 bool horizon_templated(int N);    // has a register-resident instantiation (and with it the fixed-model cache)
 
@@ -127,7 +129,9 @@ hipError_t launch_control_interp(hipStream_t st, int B, int N, double Tf, const 
 hipError_t launch_balance_order(hipStream_t st, int B, const int *work, int shift, int *order);
 hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, const double *eig, const double *A,
                              const double *B, const double *K, double umax, const double *c, int *ok_out);
+// reduction of the per-scenario records into MPC_STATS_LEN doubles; part: STATS_BLOCKS * MPC_STATS_LEN doubles of scratch
+constexpr int STATS_BLOCKS = 256;
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
-                        const int *as2, double *out16);
+                        const int *as2, const double *cl_stat, double *part, double *out);
 
 }  // namespace mpc

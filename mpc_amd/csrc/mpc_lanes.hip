@@ -970,11 +970,16 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     const double *lx = a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr;
+    // closed-loop statistics: kept in the scenario's record in memory and updated once per step (eight more values per
+    // lane would not fit the registers of this kernel)
+    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
+    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;
 
     for (int t = 0; t < nsteps; t++) {
         // ---- 1. start state, references, stage model
         double xh[6] = {0, 0, 0, 0, 0, 0};
         double dhat = 0.0;
+        double r0x = 0.0, r0y = 0.0, r0s = 0.0;       // first reference point (closed-loop statistics)
         if (a.mode == MODE_SOLVE) {
             const double *x0 = a.x0 + 7 * (size_t)s;
             xh[3] = x0[4]; xh[4] = x0[5]; xh[5] = x0[6];
@@ -1011,6 +1016,7 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
                 else step_pose(q, a.step_ramp, o);
                 to_car_frame(o, px, py, ch, sh);
                 c.at(LF_REF, k) = o[0]; c.at(LF_REF + 1, k) = o[1]; c.at(LF_REF + 2, k) = o[3];
+                if (k == 0) { r0x = o[0]; r0y = o[1]; r0s = o[3]; }
                 if (a.wp_out) {
                     double *w = a.wp_out + ((size_t)s * (N + 1) + k) * 4;
                     w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
@@ -1060,6 +1066,15 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
             const double oldx = plant[0];
             plant_rk4_c<10>(plant, u0, dt, pc);                            // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
+            if (cl_on) {
+                double *rec = a.cl_stat + CL_STAT_W * (size_t)s;
+                double acc[CL_STAT_W];
+                cl_load(acc, rec, t > 0 || a.accumulate != 0);
+                cl_before_solve(acc, dt, w_cl, r0x, r0y, r0s, xh[3], xh[4], xh[5]);
+                cl_after_step(acc, dt, w_cl[6], u0, plant[2], plant[3], plant[7], p.umax, p.dmax);
+#pragma unroll
+                for (int i = 0; i < CL_STAT_W; i++) rec[i] = acc[i];
+            }
             if (a.u_hist) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist) {
 #pragma unroll

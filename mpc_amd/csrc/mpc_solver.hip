@@ -181,8 +181,10 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W], parked plant state and coefficients
-constexpr int PARK_W = 20;
+// LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W], parked plant state and coefficients, and
+// the scenario's closed-loop statistics (PARK_CL.., kept by lane 0)
+constexpr int PARK_CL = 20;
+constexpr int PARK_W = PARK_CL + CL_STAT_W;
 template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W; }
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
 constexpr int FIXED_WPB = 4;
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
     double *s_park = wbase + 4 * (N + 1) + N * STAGE_W;   // plant state [10], plant coefficients [7], planner memory and speed while a step's solve runs
+    double *s_cl = s_park + PARK_CL;                      // closed-loop statistics of the scenario (lane 0 only)
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
@@ -285,6 +288,9 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             s_park[15] = pc.c22; s_park[16] = pc.b2;
         }
     }
+    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
+    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;     // diag of W of this scenario
+    if (cl_on && lane == 0) cl_load(s_cl, a.cl_stat + CL_STAT_W * (size_t)s, a.accumulate != 0);
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
@@ -347,6 +353,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             s_park[17] = prevp; s_park[18] = tvel;
         }
         wave_sync();
+        if (cl_on && lane == 0) cl_before_solve(s_cl, dt, w_cl, s_ref[0], s_ref[N + 1], s_ref[2 * (N + 1)], xh3, xh4, xh5);
 
         // ------------------------------------------------------------ 2. per-stage model (lane k -> stage k)
         const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;    // OFLMPC2.py:145
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             const double oldx = plant[0];
             plant_rk4_c<10>(plant, u0, dt, pc);                             // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
+            if (cl_on && lane == 0) cl_after_step(s_cl, dt, w_cl[6], u0, plant[2], plant[3], plant[7], umax, dmax);
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {
                 double val = plant[0];
@@ -555,6 +563,10 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             double *so = a.stat_out + 4 * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
+        if (cl_on) {
+#pragma unroll
+            for (int i = 0; i < CL_STAT_W; i++) a.cl_stat[CL_STAT_W * (size_t)s + i] = s_cl[i];
+        }
     }
     if (!pull) return;
     wave_sync();            // the wave's LDS areas are reused by its next scenario
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
 // gradient depends on the step's data.  One wavefront; a set-up cost of about 3N+5 triangular solve pairs.
 template <int N>
 __global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, double vx, double *H, double *Kref, double *Kx,
-                                                         double *T)
+                                                         double *T, double *resid_out)
 {
     const int lane = threadIdx.x;
     const bool valid = lane < N;
@@ -611,12 +623,24 @@ __global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, doubl
     }
     // table of the active-set solve (mpc_aset.hpp): G = inv(H), G P' and P G P' with P = dt * (prefix-sum rows), as one
     // symmetric 2N x 2N matrix [[G, G P'], [P G, P G P']]; column c of G is one solve with a unit vector
+    // The active-set solve certifies its points through this table alone, so the table is checked against H here:
+    // resid_out[0] = the largest entry of |H G - I| (the launcher switches the method off when it is too large).
+    double rmax = 0.0;
     if (T) {
         constexpr int LD = 2 * N;
         double run = 0.0;
 #pragma unroll 1
         for (int c = 0; c < N; c++) {
             const double x = nt.solve(lane == c ? 1.0 : 0.0, lane);      // lane i: G[i][c]
+            {
+                double hx0 = 0.0, hx1 = 0.0;                              // row `lane` of H (= its column: symmetric) against x
+#pragma unroll 1
+                for (int j = 0; j < N; j += 2) {
+                    hx0 = fma(valid ? H[j * N + lane] : 0.0, bcast(x, j), hx0);
+                    if (j + 1 < N) hx1 = fma(valid ? H[(j + 1) * N + lane] : 0.0, bcast(x, j + 1), hx1);
+                }
+                if (valid) rmax = fmax(rmax, fabs(hx0 + hx1 - (lane == c ? 1.0 : 0.0)));
+            }
             run += valid ? x : 0.0;
             const double gp = dt * run;                                    // lane i: (G P')[i][c]
             const double pgp = dt * incl_prefix(valid ? gp : 0.0, lane);   // lane k: (P G P')[k][c]
@@ -628,19 +652,21 @@ __global__ __launch_bounds__(WAVE) void k_condense_fixed(const DevCfg cfg, doubl
             }
         }
     }
+    rmax = wave_max(rmax);
+    if (resid_out && lane == 0) resid_out[0] = rmax;
 }
 
 template <int N>
-static hipError_t launch_fixed_n(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st)
+static hipError_t launch_fixed_n(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, double *resid, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_condense_fixed<N>, dim3(1), dim3(WAVE), 0, st, cfg, vx, H, Kref, Kx, T);
+    hipLaunchKernelGGL(k_condense_fixed<N>, dim3(1), dim3(WAVE), 0, st, cfg, vx, H, Kref, Kx, T, resid);
     return hipGetLastError();
 }
 
-hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, hipStream_t st)
+hipError_t launch_condense_fixed(const DevCfg &cfg, double vx, double *H, double *Kref, double *Kx, double *T, double *resid, hipStream_t st)
 {
     switch (cfg.N) {
-#define MPC_CASE(n) case n: return launch_fixed_n<n>(cfg, vx, H, Kref, Kx, T, st);
+#define MPC_CASE(n) case n: return launch_fixed_n<n>(cfg, vx, H, Kref, Kx, T, resid, st);
         MPC_HORIZONS(MPC_CASE)
 #undef MPC_CASE
     default: return hipErrorInvalidValue;

@@ -22,3 +22,18 @@ def allreduce_stats(sums: torch.Tensor, maxima: torch.Tensor, group=None) -> tup
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(maxima, op=dist.ReduceOp.MAX, group=group)
     return sums, maxima
+
+
+def allreduce_solver_stats(stats: dict, device=None, group=None) -> dict:
+    """The dictionary a controller's stats() returns (the slots of mpc_get_stats: solver counters, and the cost and
+    constraint-violation statistics of the last closed-loop run) combined over the ranks: keys starting with "max_" take
+    the maximum, every other key adds.  One SUM and one MAX all-reduce; the identity outside a process group."""
+    keys = sorted(stats)
+    mk = [k for k in keys if k.startswith("max_")]
+    sk = [k for k in keys if not k.startswith("max_")]
+    sv = torch.tensor([float(stats[k]) for k in sk], dtype=torch.float64, device=device)
+    mv = torch.tensor([float(stats[k]) for k in mk], dtype=torch.float64, device=device)
+    allreduce_stats(sv, mv, group)
+    out = dict(zip(sk, sv.tolist()))
+    out.update(zip(mk, mv.tolist()))
+    return out

@@ -71,9 +71,13 @@ class Oracle:
         L.orc_skidpad_run.argtypes = [_dp, _dp, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, C.c_double, C.c_double,
                                       C.c_int]
         L.orc_skidpad_run.restype = C.c_long
+        L.orc_skidpad_run_cl.argtypes = L.orc_skidpad_run.argtypes + [_dp, _dp, _dp]
+        L.orc_skidpad_run_cl.restype = C.c_long
         L.orc_ofl_run.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp,
                                   _ip, C.c_double, C.c_double, C.c_int]
         L.orc_ofl_run.restype = C.c_long
+        L.orc_ofl_run_cl.argtypes = L.orc_ofl_run.argtypes + [_dp]
+        L.orc_ofl_run_cl.restype = C.c_long
         L.orc_set_unconstrained_first.argtypes = [C.c_int]
         L.orc_set_terminal_set.argtypes = [C.c_int, _dp]
         L.orc_set_terminal_set.restype = C.c_int
@@ -189,20 +193,27 @@ class Oracle:
                                        _ptr(lin_u), _ptr(u0), _ptr(info), tol[0], tol[1], tol[2])
         return st, st8, lp.value, float(pp[0]), float(u0[0]), info
 
-    def skidpad_run(self, cfg, states, laps, prev_progress, target_vel, nsteps, record=True, tol=None):
-        """states (B,8) / laps (B,) int32 / prev_progress (B,) are updated in place."""
+    def skidpad_run(self, cfg, states, laps, prev_progress, target_vel, nsteps, record=True, tol=None, lin_x=None, lin_u=None,
+                    cl_stats=None):
+        """states (B,8) / laps (B,) int32 / prev_progress (B,) are updated in place.  lin_x (B,6,N+1) / lin_u (B,N): the
+        controllers' carried memory (LPV prev_x / prev_u, NL iterate in lin_u), read and updated, so that a run can be
+        continued by the next call; cl_stats (B,8): receives the closed-loop statistics of this call (CL_KEYS)."""
         tol = tol or self.tol
         B = states.shape[0]
         assert states.flags.c_contiguous and laps.dtype == np.int32
+        for a in (lin_x, lin_u, cl_stats):
+            assert a is None or (a.flags.c_contiguous and a.dtype == np.float64)
         uh = np.zeros((nsteps, B)) if record else None
-        iters = self.lib.orc_skidpad_run(_ptr(cfg), _ptr(states), laps.ctypes.data_as(_ip), _ptr(prev_progress),
-                                         float(target_vel), B, int(nsteps), _ptr(uh), tol[0], tol[1], tol[2])
+        iters = self.lib.orc_skidpad_run_cl(_ptr(cfg), _ptr(states), laps.ctypes.data_as(_ip), _ptr(prev_progress),
+                                            float(target_vel), B, int(nsteps), _ptr(uh), tol[0], tol[1], tol[2], _ptr(lin_x),
+                                            _ptr(lin_u), _ptr(cl_stats))
         return uh, int(iters)
 
 
-    def ofl_run(self, cfg, x10, est, P, target_vel, nsteps, noise=None, ramp_length=0.0, record=True, tol=None):
+    def ofl_run(self, cfg, x10, est, P, target_vel, nsteps, noise=None, ramp_length=0.0, record=True, tol=None, cl_stats=None):
         """simulator.py:206-281 for B scenarios: x10 / est (B,10) and P (B,10,10) are updated in place; noise (n,B,7)
-        is added to the measurements.  Returns (u (n,B), x (n,B,10), est (n,B,10), status (B,), iterations)."""
+        is added to the measurements; cl_stats (B,8) receives the closed-loop statistics (CL_KEYS).
+        Returns (u (n,B), x (n,B,10), est (n,B,10), status (B,), iterations)."""
         tol = tol or self.tol
         B = x10.shape[0]
         assert x10.flags.c_contiguous and est.flags.c_contiguous and P.flags.c_contiguous
@@ -212,9 +223,10 @@ class Oracle:
         status = np.zeros(B, np.int32)
         nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
         assert nz is None or nz.shape == (nsteps, B, 7)
-        iters = self.lib.orc_ofl_run(_ptr(cfg), _ptr(x10), _ptr(est), _ptr(P), float(target_vel), B, int(nsteps), _ptr(nz),
-                                     _ptr(EKF_Q_DIAG), _ptr(EKF_R_DIAG), float(ramp_length), _ptr(uh), _ptr(xh), _ptr(eh),
-                                     status.ctypes.data_as(_ip), tol[0], tol[1], tol[2])
+        assert cl_stats is None or (cl_stats.flags.c_contiguous and cl_stats.shape == (B, 8))
+        iters = self.lib.orc_ofl_run_cl(_ptr(cfg), _ptr(x10), _ptr(est), _ptr(P), float(target_vel), B, int(nsteps), _ptr(nz),
+                                        _ptr(EKF_Q_DIAG), _ptr(EKF_R_DIAG), float(ramp_length), _ptr(uh), _ptr(xh), _ptr(eh),
+                                        status.ctypes.data_as(_ip), tol[0], tol[1], tol[2], _ptr(cl_stats))
         return uh, xh, eh, status, int(iters)
 
     def set_terminal_set(self, C=None):
@@ -228,6 +240,11 @@ class Oracle:
     def set_unconstrained_first(self, on: bool):
         """Timed CPU baseline only: try the unconstrained minimiser (one Riccati pass) before the interior point."""
         self.lib.orc_set_unconstrained_first(int(bool(on)))
+
+
+# columns of the closed-loop statistics (cl_update in mpc_oracle.c)
+CL_KEYS = ("stage_cost", "lateral_error_sq", "heading_pair_violation", "input_sq", "max_bound_violation",
+           "max_heading_pair_violation", "max_predicted_heading_pair_violation", "steps")
 
 
 # EKF.py:28-32: P0, Q and R = diag(sigma) of CarEKF

@@ -24,7 +24,12 @@ def _worker(rank, world, port, total, q):
     sums = torch.tensor([float(len(owned)), float(owned.sum())], dtype=torch.float64)
     maxima = torch.tensor([float(owned.max()), 10.0 * (rank + 1)], dtype=torch.float64)
     allreduce_stats(sums, maxima)
-    q.put((rank, lo, hi, sums.tolist(), maxima.tolist()))
+    # the dictionary of a controller's stats() (cost and constraint-violation statistics included), fabricated per rank
+    from mpc_amd import _lib
+    from mpc_amd.sharding import allreduce_solver_stats
+    mine = {k: (1e-3 * (rank + 1) if k.startswith("max_") else float(len(owned)) * (i + 1)) for i, k in _lib.STATS_SLOTS.items()}
+    red = allreduce_solver_stats(mine)
+    q.put((rank, lo, hi, sums.tolist(), maxima.tolist(), red))
     dist.destroy_process_group()
 
 
@@ -40,7 +45,14 @@ def test_shards_cover_and_statistics_reduce_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, s0, m0), (r1, lo1, hi1, s1, m1) = out
+    (r0, lo0, hi0, s0, m0, d0), (r1, lo1, hi1, s1, m1, d1) = out
+    from mpc_amd import _lib
+    assert d0 == d1 and set(d0) == set(_lib.STATS_SLOTS.values())
+    for i, k in _lib.STATS_SLOTS.items():                           # maxima take the larger rank's value, the rest add
+        assert d0[k] == pytest.approx(2e-3 if k.startswith("max_") else float(total) * (i + 1)), k
+    assert {_lib.STATS_SLOTS[i] for i in _lib.STATS_MAX_SLOTS} == {k for k in d0 if k.startswith("max_")}
+    for k in ("sum_stage_cost", "sum_lateral_error_sq", "max_bound_violation", "max_heading_pair_violation"):
+        assert k in d0                                              # the statistics the runs are judged by travel too
     assert (lo0, hi0, lo1, hi1) == (0, 2049, 2049, 4097)            # contiguous, disjoint, complete
     assert s0 == s1 == [float(total), float(total * (total - 1) // 2)]
     assert m0 == m1 == [float(total - 1), 20.0]
@@ -84,6 +96,8 @@ def test_bench_starts_its_own_ranks_and_reduces_through_the_sharding_helper():
     assert s["scenario_steps"] == 2 * 4096 * 20                     # SUM over the ranks
     assert m["elapsed_s"] == 2.0 and m["max_abs_u0"] == 0.2         # MAX over the ranks (rank 1 reports 2.0 s)
     assert d["value"] == s["scenario_steps"] / m["elapsed_s"]       # whole-job units over the slowest rank's time
+    assert s["stage_cost"] == pytest.approx(3.0 * 2 * 4096 * 20) and s["closed_loop_steps"] == 2 * 4096 * 20
+    assert m["max_heading_pair_violation"] == 2e-14 and m["max_bound_violation"] == 0.0
 
 
 def test_reduce_statistics_is_identity_for_one_rank():

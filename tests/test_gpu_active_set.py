@@ -119,3 +119,43 @@ def test_fused_launch_equals_per_step_launches_bit_for_bit():
     assert torch.equal(a.state, b.state)
     sa, sb = a.ocp.stats(), b.ocp.stats()
     assert sa["n_active_set_solves"] > 0
+
+
+@pytest.mark.parametrize("scale_q,scale_r", [(100.0, 0.01), (0.01, 100.0), (1e4, 1e-3)])
+def test_stiff_weights_at_the_longest_horizon(orc80, scale_q, scale_r):
+    """Weights far from the parameter file's (state weights q and input weight r moved apart or together by 1e4 .. 1e7) at
+    N = 64: the table inv(H) the method certifies its points through is checked against H when it is built
+    (mpc_get_stats: max_table_residual); where it is not accurate enough the method stays off.  Either way every step
+    matches the 80-bit checker."""
+    import copy
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    N, Tf, nsteps, B = 64, 0.64, 40, 48
+    params = copy.deepcopy(O.load_params("L"))
+    params["controller"]["q"] *= scale_q
+    params["controller"]["r"] *= scale_r
+    cfg = O.make_cfg("L", N, Tf, params=params)
+    umax = cfg[10]
+    st = _starts(B, 21)
+    sim = SkidpadBatch(N, Tf, st, model="L", params=params)
+    xs, us = sim.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    xs = xs.cpu().numpy(); us = us.cpu().numpy()
+    assert (sim.status.cpu().numpy() == 0).all()
+    stats = sim.ocp.stats()
+    off = stats["max_table_residual"] > 1e-9
+    assert stats["n_active_set_switched_off"] == float(off)
+    assert off == (scale_q / scale_r >= 1e4)           # cond(H) 1.5e9 and 3e10 against 1.6e5 with the file's weights
+    if off:
+        assert stats["n_active_set_solves"] == 0 and stats["n_constrained"] > 0
+    elif stats["n_constrained"] > 0:
+        assert stats["n_active_set_solves"] > 0
+    for b in range(0, B, 4):
+        lap = 0
+        for t in range(nsteps):
+            x = st[b] if t == 0 else xs[t - 1, b]
+            _, _, _, _, u_ref, _ = orc80.skidpad_step(cfg, x.copy(), lap, 0.0, 8.0)
+            assert abs(us[t, b] - u_ref) <= _tol(u_ref, umax), (scale_q, scale_r, b, t, us[t, b], u_ref, stats["max_table_residual"])
+            if xs[t, b, 0] > 16.75 and x[0] <= 16.75:
+                lap += 1
