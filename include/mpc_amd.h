@@ -72,8 +72,12 @@ typedef struct mpc_config {
     double w[7];         /* diag of W = blkdiag(Q*q, R*r); stage cost is dt * 1/2 |y-yref|^2_W */
     double We[36];       /* terminal weight on the 6 states (row-major)                       */
     double eps;          /* tyre-model denominator offset (1e-3)                              */
-    double tol_mu;       /* interior-point stop: complementarity                              */
-    double tol_res;      /* interior-point stop: stationarity / feasibility residual           */
+    double tol_mu;       /* interior-point stop: complementarity (default 1e-15)                                          */
+    double tol_res;      /* interior-point stop: stationarity / feasibility residual, relative (default 1e-12).  A solve also
+                          * ends with status 0 at an iterate inside the acceptance band mu <= 10 tol_mu and residual <=
+                          * 1e3 tol_res when the residual has stopped halving, when mu has fallen below 1e-3 tol_mu, at the
+                          * iteration cap, or when the next iterate is worse or not finite (rounding sets the floor there:
+                          * inputs within 1e-9 of the minimiser); mpc_get_stats [6], [7] report what was reached. */
     int max_iter;        /* interior-point iteration cap                                      */
     int lpv_lin_prev;    /* LPV only: 0 = lin_mode "reference", 1 = "prev_iter" (LPVMPC.py:254) */
     /* MPC_KIND_NL only (w, We, eps above are not read for it); NLMPC.py:159-186 hard-codes
@@ -160,7 +164,9 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
  * with MPC_EINVAL.  Kinds L and OFL (cfg->B, the cache and the warm start do not apply: every solve condenses its own
  * problem and starts cold, so the results equal mpc_solve_only's on a handle without fixed-model cache bit for bit).
  * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams, two threads) race; issue them
- * one after the other.  Arguments as mpc_solve_only; errors are read with mpc_last_error(NULL). */
+ * one after the other.  The first call on each GPU looks the array's address up (hipGetSymbolAddress, which may also load
+ * the library's code object on that GPU): make one call per GPU outside graph capture before capturing.  Arguments as
+ * mpc_solve_only; errors are read with mpc_last_error(NULL). */
 #define MPC_NOALLOC_MAX_B 64
 #define MPC_NOALLOC_MAX_N 64
 int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const double *x0, const double *wp, const double *p,
@@ -293,9 +299,10 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream);
  *   [16] sum of the stage cost at the start of the horizon with the applied input, dt * 1/2 |[x0; u0] - yref_0|^2_W
  *        (per-scenario weights where mpc_set_cost_weights gave them; the NL controller's W for MPC_KIND_NL),
  *   [17] sum of the squared lateral offset of the first reference point in the car frame (tracking error),
- *   [18] sum and [21] max of | |(cos, sin)| - 1 | of the plant's heading pair after each step,
+ *   [18] sum and [21] max of | |(cos, sin)| - 1 | of the plant's heading pair at the start of each step,
  *   [19] sum of the squared applied inputs,
- *   [20] max excess of |u0| over the rate bound or of the plant's steering angle over its bound (0: never exceeded),
+ *   [20] max excess of |u0| over the rate bound or of the plant's steering angle (at the start of a step) over its
+ *        bound (0: never exceeded),
  *   [22] max of | |(cos, sin)| - 1 | over the predicted trajectories (MPC_KIND_NL, where the pair is a model state; the
  *        linear controllers rebuild the pair from the angle: 0),
  *   [23] scenario-steps counted; rest reserved.

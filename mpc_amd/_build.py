@@ -35,6 +35,11 @@ def _dev_env() -> bool:
     return bool(os.environ.get("MPC_DEV_HORIZONS") or os.environ.get("MPC_DEV_DEFINES"))
 
 
+def developer_build_left_behind() -> bool:
+    """The in-tree library was built with MPC_DEV_* set and this process runs without them."""
+    return os.path.exists(LIB_PATH) and os.path.exists(DEV_MARK) and not _dev_env()
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

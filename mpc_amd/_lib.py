@@ -86,10 +86,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path):
+    if os.environ.get("MPC_AMD_LIBRARY"):
+        if not os.path.exists(path):
+            raise RuntimeError(f"MPC_AMD_LIBRARY names {path}, which does not exist")
+    elif not os.path.exists(path) or _build.developer_build_left_behind():
+        # absent, or a developer build (a subset of the horizons, experiment macros) that a plain run must not load
         if not build_if_missing:
-            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (needs hipcc)")
-        _build.build_library()
+            raise RuntimeError(f"{path} is missing or a developer build: run __graft_entry__.build() (needs hipcc)")
+        _build.build_library(force=True)
     lib = C.CDLL(path)
     for name, (args, res) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = the build is out of date

@@ -16,7 +16,7 @@ struct mpc_handle {
     double *Hws = nullptr;       // B * N * N condensed Hessians (wave layout)
     int *sqp = nullptr;          // B SQP iteration counts of the last NL call
     double *ipm_ws = nullptr;    // B interior-point warm-start records (NULL: cold starts only)
-    double *stat = nullptr;      // B * 4 solver records
+    double *stat = nullptr;      // B * STAT_W solver records and closed-loop statistics
     int *iters = nullptr, *status = nullptr;   // used when the caller passes no output arrays
     int *work = nullptr, *order = nullptr;     // load balance of chained launches: last launch's iterations, scenario order
     int *queue = nullptr;                      // work queue counters of the fixed-model kernel (two ints, zero between launches)
@@ -27,8 +27,7 @@ struct mpc_handle {
     int term_m = 0;
     bool px_free = false;        // nothing weighs the longitudinal position (controller weights, or every row of cost_scen)
     double *stats_out = nullptr; // device result of the statistics reduction (MPC_STATS_LEN) and its per-workgroup partial vectors
-    double *cl_stat = nullptr;   // B * 8 closed-loop statistics of the last closed-loop call
-    bool cl_valid = false;       // the last call was a closed-loop call (cl_stat belongs to it)
+    bool cl_valid = false;       // the last call was a closed-loop call (the closed-loop part of `stat` belongs to it)
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
     double *sh_T = nullptr;      // table of the active-set solve (part of the cache; NULL with qp_method = interior point)
     double sh_T_resid = 0.0;     // largest entry of |H inv(H) - I| of that table (checked when it is built)
@@ -92,7 +91,7 @@ extern "C" {
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 // Argument checks shared by mpc_create and the handle-free entry point; returns NULL when the definition is usable.
-static const char *check_config(const mpc_config *cfg)
+static const char *check_config(const mpc_config *cfg, bool with_workspace = true)
 {
     static thread_local char buf[160];
     if (cfg->kind < MPC_KIND_L || cfg->kind > MPC_KIND_NL) return "unknown kind";
@@ -100,7 +99,7 @@ static const char *check_config(const mpc_config *cfg)
         snprintf(buf, sizeof buf, "horizon N=%d is outside 2..%d", cfg->N, MPC_MAX_HORIZON);
         return buf;
     }
-    if (cfg->B < 1 || !(cfg->dt > 0.0)) return "need B >= 1 and dt > 0";
+    if ((with_workspace && cfg->B < 1) || !(cfg->dt > 0.0)) return "need B >= 1 and dt > 0";
     if (!(cfg->step_ramp_length >= 0.0)) return "step_ramp_length must be >= 0";
     if (cfg->kind == MPC_KIND_NL) {
         if (!mpc::nl_horizon_capacity(cfg->N)) return "the NL controller needs a horizon of 2..64";
@@ -155,7 +154,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     const size_t B = (size_t)cfg->B, N = (size_t)(cfg->kind == MPC_KIND_NL ? mpc::nl_horizon_capacity(cfg->N) : cfg->N);
     if (e == hipSuccess && !h->lanes) e = hipMalloc(&h->Hws, B * N * N * sizeof(double));
     if (e == hipSuccess && h->lanes) e = hipMalloc(&h->lane_ws, mpc::lanes_workspace_doubles(cfg->N, cfg->B, 0) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&h->stat, B * 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->stat, B * mpc::STAT_W * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(h->stat, 0, B * mpc::STAT_W * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->status, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->work, B * sizeof(int));
@@ -169,8 +169,6 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->stats_out, (size_t)(1 + mpc::STATS_BLOCKS) * MPC_STATS_LEN * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&h->cl_stat, B * mpc::CL_STAT_W * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(h->cl_stat, 0, B * mpc::CL_STAT_W * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->as2, B * 6 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->as2, 0, B * 6 * sizeof(int));
     if (e != hipSuccess) {
@@ -187,7 +185,7 @@ void mpc_destroy(mpc_handle *h)
     if (!h) return;
     DeviceScope scope(h->cfg.device);
     (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
-    (void)hipFree(h->stats_out); (void)hipFree(h->cl_stat); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
+    (void)hipFree(h->stats_out); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T); (void)hipFree(h->as2);
     (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
     delete h;
@@ -327,6 +325,12 @@ static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStr
 // its arithmetic.
 static const int BAL_CHUNK = 1024, BAL_MIN_B = 1024, BAL_MIN_STEPS = 4;
 
+// true when the launch goes to the work-queue form of the fixed-model kernel (the only reader of SolveArgs::queue)
+static bool launches_work_queue(const mpc_handle *h, const mpc::SolveArgs &a)
+{
+    return h->cfg.kind != MPC_KIND_NL && !h->lanes && a.sh_H && a.sh_exclusive && mpc::horizon_templated(h->cfg.N);
+}
+
 static hipError_t launch_chain(mpc_handle *h, const mpc::SolveArgs &a, hipStream_t st)
 {
     mpc::SolveArgs c = a;
@@ -348,7 +352,13 @@ static hipError_t launch_chain(mpc_handle *h, const mpc::SolveArgs &a, hipStream
         const bool rank = c.nsteps >= BAL_MIN_STEPS;            // a short launch says little and the sort is not free
         c.work_out = rank ? h->work : nullptr;
         c.queue = c.nsteps >= 2 ? h->queue : nullptr;           // one step per launch: every wave has the same short job
-        hipError_t e = launch_for_kind(h, c, st);
+        hipError_t e = hipSuccess;
+        // The last wave to leave a work-queue launch puts the counters back to zero; a launch that was cut short (a fault,
+        // a reset) would leave them set and the next launch's waves would find nothing to do.  Start every such launch
+        // from zero whatever came before.
+        if (c.queue && launches_work_queue(h, c)) e = hipMemsetAsync(h->queue, 0, 2 * sizeof(int), st);
+        if (e != hipSuccess) return e;
+        e = launch_for_kind(h, c, st);
         if (e != hipSuccess) return e;
         if (rank) {
             e = mpc::launch_balance_order(st, a.B, h->work, shift, h->order);
@@ -421,7 +431,7 @@ int mpc_closed_loop_run(mpc_handle *h, void *stream, int B, int planner, int nst
     a.lin_x = lin_x; a.lin_u = lin_u; a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
     a.U_out = U_out; a.traj_out = traj_out; a.u0_out = u0_out; a.wp_out = wp_out;
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
-    a.stat_out = h->stat; a.cl_stat = h->cl_stat;
+    a.stat_out = h->stat;
     attach_cache(h, a);
     h->last_B = B; h->cl_valid = true;
     HIP_TRY(h, launch_chain(h, a, (hipStream_t)stream));
@@ -446,7 +456,7 @@ int mpc_ofl_closed_loop_run(mpc_handle *h, void *stream, int B, int nsteps, doub
     for (int i = 0; i < 7; i++) a.ekf_r[i] = r_diag_host[i];
     a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws; a.u0_out = u0_out; a.u_hist = u_hist; a.x_hist = x_hist; a.est_hist = est_hist;
     a.status_out = status_out; a.iters_out = iters_out; a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
-    a.stat_out = h->stat; a.cl_stat = h->cl_stat;
+    a.stat_out = h->stat;
     attach_cache(h, a);
     // The active-set solve runs here too (MPC_QP_AUTO): on noisy estimates the active sets are large and jump from step to
     // step, a third of the attempts are handed on and the gain is small (8192 scenarios x 300 steps with the EKF's
@@ -477,7 +487,7 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream)
 // current, and only that address (never the array's name, which in host code is a host-side stand-in) goes to kernels.
 constexpr int NOALLOC_MAX_B = MPC_NOALLOC_MAX_B, NOALLOC_MAX_N = MPC_NOALLOC_MAX_N;
 constexpr size_t NOALLOC_H_DOUBLES = (size_t)NOALLOC_MAX_B * NOALLOC_MAX_N * NOALLOC_MAX_N;      // condensed Hessians
-constexpr size_t NOALLOC_STAT_DOUBLES = (size_t)NOALLOC_MAX_B * 4;                               // solver records
+constexpr size_t NOALLOC_STAT_DOUBLES = (size_t)NOALLOC_MAX_B * mpc::STAT_W;                             // solver records
 constexpr size_t NOALLOC_INT_DOUBLES = (size_t)NOALLOC_MAX_B;                                    // 2 * MAX_B ints: iterations, status
 constexpr size_t NOALLOC_DOUBLES = NOALLOC_H_DOUBLES + NOALLOC_STAT_DOUBLES + NOALLOC_INT_DOUBLES;
 static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
@@ -487,7 +497,7 @@ int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const dou
                            const double *d_hat, double *U_out, double *traj_out, int *status_out, int *iters_out)
 {
     if (!cfg) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: null configuration");
-    if (const char *why = check_config(cfg)) return fail(nullptr, MPC_EINVAL, std::string("mpc_solve_only_noalloc: ") + why);
+    if (const char *why = check_config(cfg, false)) return fail(nullptr, MPC_EINVAL, std::string("mpc_solve_only_noalloc: ") + why);   // cfg->B sizes a handle's workspace: not read here
     if (cfg->kind != MPC_KIND_L && cfg->kind != MPC_KIND_OFL)
         return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: kinds L and OFL only (LPV and NL carry state between calls: use a handle)");
     if (!mpc::horizon_templated(cfg->N) || cfg->N > NOALLOC_MAX_N)
@@ -528,7 +538,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host_out)
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
     ON_HANDLE_DEVICE(h);
     HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->as2,
-                                 h->cl_valid ? h->cl_stat : nullptr, h->stats_out + MPC_STATS_LEN, h->stats_out));
+                                 h->cl_valid, h->dev, h->cost_scen, h->stats_out + MPC_STATS_LEN, h->stats_out));
     HIP_TRY(h, hipMemcpyAsync(host_out, h->stats_out, MPC_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     host_out[14] = h->sh_on && h->sh_T ? h->sh_T_resid : 0.0;

@@ -509,24 +509,31 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
 constexpr int ST_N = MPC_STATS_LEN;
 __device__ __forceinline__ bool stat_is_max(int c) { return (c >= 5 && c <= 7) || (c >= 20 && c <= 22); }
 
+// diag of W as the stage cost of the closed-loop statistics needs it: per scenario from cost_scen, else the controller's
+struct StatWeights { int nl; double half_dt, umax, dmax; double w[8]; };
+
 __global__ __launch_bounds__(256) void k_stats_partial(int B, const double *stat, const int *iters, const int *status,
-                                                        const int *sqp, const int *as2, const double *cl, double *part)
+                                                        const int *sqp, const int *as2, bool with_cl, StatWeights sw,
+                                                        const double *cost_scen, double *part)
 {
     __shared__ double sh[ST_N][256 + 1];
     double acc[ST_N];
 #pragma unroll
     for (int c = 0; c < ST_N; c++) acc[c] = 0.0;
     for (int s = blockIdx.x * 256 + threadIdx.x; s < B; s += gridDim.x * 256) {
-        const double *q = stat + 4 * (size_t)s;
+        const double *q = stat + STAT_W * (size_t)s;
         acc[0] += 1.0; acc[1] += iters[s]; acc[2] += (status[s] != 0); acc[3] += q[2]; acc[4] += q[3];
         acc[5] = fmax(acc[5], q[3]);
         if (q[2] != 0.0) { acc[6] = fmax(acc[6], q[0]); acc[7] = fmax(acc[7], q[1]); }
         if (sqp) acc[8] += sqp[s];
         if (as2) { acc[9] += as2[6 * s]; acc[10] += as2[6 * s + 1]; acc[11] += as2[6 * s + 2]; acc[12] += as2[6 * s + 3]; acc[13] += 64.0 * as2[6 * s + 4]; }
-        if (cl) {
-            const double *r = cl + CL_STAT_W * (size_t)s;
-            acc[16] += r[CL_COST]; acc[17] += r[CL_EY2]; acc[18] += r[CL_TRIG_SUM]; acc[19] += r[CL_U2];
-            acc[20] = fmax(acc[20], r[CL_BOUND_MAX]); acc[21] = fmax(acc[21], r[CL_TRIG_MAX]); acc[22] = fmax(acc[22], r[CL_PRED_TRIG_MAX]);
+        if (with_cl) {
+            const double *r = q + STAT_CL;
+            double cost = 0.0;                            // sum over the steps of dt/2 |[x0; u0] - yref_0|^2_W
+#pragma unroll
+            for (int c = 0; c < 8; c++) cost += ((cost_scen && c < 7) ? cost_scen[43 * (size_t)s + c] : sw.w[c]) * r[CL_ERR + c];
+            acc[16] += sw.half_dt * cost; acc[17] += r[CL_ERR + 1]; acc[18] += r[CL_TRIG_SUM]; acc[19] += r[CL_ERR + (sw.nl ? 7 : 6)];
+            acc[20] = fmax(acc[20], fmax(r[CL_U_MAX] - sw.umax, r[CL_STEER_MAX] - sw.dmax)); acc[21] = fmax(acc[21], r[CL_TRIG_MAX]); acc[22] = fmax(acc[22], r[CL_PRED_TRIG_MAX]);
             acc[23] += r[CL_STEPS];
         }
     }
@@ -552,11 +559,15 @@ __global__ __launch_bounds__(64) void k_stats_final(int nblocks, const double *p
 }
 
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
-                        const int *as2, const double *cl_stat, double *part, double *out)
+                        const int *as2, bool with_closed_loop, const DevCfg &cfg, const double *cost_scen, double *part, double *out)
 {
     int nblocks = (B + 255) / 256;
     if (nblocks > STATS_BLOCKS) nblocks = STATS_BLOCKS;
-    hipLaunchKernelGGL(k_stats_partial, dim3(nblocks), dim3(256), 0, st, B, stat, iters, status, sqp, as2, cl_stat, part);
+    StatWeights sw;
+    sw.nl = cfg.kind == MPC_KIND_NL; sw.half_dt = 0.5 * cfg.dt; sw.umax = cfg.max_rate; sw.dmax = cfg.max_steering;
+    for (int c = 0; c < 8; c++) sw.w[c] = sw.nl ? cfg.w_nl[c] : (c < 7 ? cfg.w[c] : 0.0);
+    hipLaunchKernelGGL(k_stats_partial, dim3(nblocks), dim3(256), 0, st, B, stat, iters, status, sqp, as2, with_closed_loop, sw,
+                       sw.nl ? nullptr : cost_scen, part);
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, nblocks, part, out);
     return hipGetLastError();
 }

@@ -170,50 +170,59 @@ __device__ __forceinline__ void plant_rk4(double *x, double u, double dt, const 
 }
 
 // ---------------------------------------------------------------- closed-loop statistics
-// What a batch of closed loops is judged by, per scenario, over the steps of one entry-point call (the kernels keep the
-// eight values on chip and write them once; mpc_get_stats reduces them over the scenarios):
-//   CL_COST      sum of the controller's own stage cost at the start of the horizon with the input that was applied,
-//                dt * 1/2 |[x0; u0] - yref_0|^2_W (LMPC2.py:220-253 with acados' scaling by the time step; x0 is the
-//                car-frame start state, yref_0 the first reference point)
-//   CL_EY2       sum of the squared lateral offset of the first reference point in the car frame (the tracking error)
-//   CL_U2        sum of the squared applied input
-//   CL_TRIG_SUM / CL_TRIG_MAX   | |(cos, sin)| - 1 | of the plant's heading pair after the step (the plant does not
-//                renormalise it; skidpad_simulator.py:134 prints the same quantity for the predicted trajectory)
+// What a batch of closed loops is judged by, per scenario, over the steps of one entry-point call.  The kernels keep
+// CL_STAT_W running values per scenario and write them once per launch; the statistics kernel turns them into the
+// quantities mpc_get_stats reports (the stage cost needs the weights, which the step loops therefore never touch):
+//   CL_ERR .. CL_ERR + 7   sums of the squared components of [x0; u0] - yref_0 at the start of the horizon, x0 the
+//                car-frame start state, u0 the applied input, yref_0 the first reference point.  Linear controllers
+//                (LMPC2.py:220-253, 290-298): (x_ref, y_ref, sin psi_ref, vy, r, delta, u0, -); NL controller
+//                (NLMPC.py:159-186, 208-216): (x_ref, y_ref, 1 - cos psi_ref, sin psi_ref, vy, r, delta, u0).
+//                The stage cost of a step is dt * 1/2 * sum_c w_c e_c^2; e_1 is the lateral tracking error.
+//   CL_TRIG_SUM / CL_TRIG_MAX   | |(cos, sin)| - 1 | of the plant's heading pair at the start of the step (the plant does
+//                not renormalise it; skidpad_simulator.py:134 prints the same quantity for the predicted trajectory)
 //   CL_PRED_TRIG_MAX   the same over the predicted trajectory, where the pair is a state of the model (NL controller;
 //                the linear controllers rebuild the pair from the angle, so it lies on the unit circle to rounding)
-//   CL_BOUND_MAX  largest excess of |u0| over the rate bound or of the plant's steering angle over its bound (0: none)
+//   CL_U_MAX, CL_STEER_MAX   largest |u0| and largest |steering angle| of the plant (at the start of a step); the
+//                statistics kernel reports their excess over the rate and the angle bound (the bounds, like the weights,
+//                stay out of the step loops: two more wave-uniform values alive across the solve are scalar-register
+//                spills on every step)
+// Everything a step contributes is known once its input is: nothing here waits for the plant's RK4 step, whose chain of
+// dependent operations ends the closed-loop step (a wave per scenario is latency-bound there).
 //   CL_STEPS     steps counted
-constexpr int CL_STAT_W = 8;
-enum { CL_COST = 0, CL_EY2 = 1, CL_TRIG_SUM = 2, CL_U2 = 3, CL_BOUND_MAX = 4, CL_TRIG_MAX = 5, CL_PRED_TRIG_MAX = 6, CL_STEPS = 7 };
+constexpr int CL_STAT_W = 14;
+enum { CL_ERR = 0, CL_TRIG_SUM = 8, CL_STEPS = 9, CL_U_MAX = 10, CL_TRIG_MAX = 11, CL_PRED_TRIG_MAX = 12, CL_STEER_MAX = 13 };
 
-// The part known before the solve: the state and reference terms of the stage cost (w: diag of W, 6 state weights then
-// the input's) and the tracking error.  r0x, r0y, r0s: first reference point (x, y, sin psi); x0 = (0, 0, 0, vy, r, delta).
-__device__ __forceinline__ void cl_before_solve(double *acc, double dt, const double *w, double r0x, double r0y, double r0s,
-                                                double vy, double r, double delta)
+// | |(hc, hs)| - 1 | of a heading pair.  Near the unit circle (always, in practice: the pair drifts by rounding only)
+// sqrt(1 + d) - 1 is summed as a series in d = hc^2 + hs^2 - 1, exact to 4e-10 of the value for |d| < 0.01; the closed
+// loops are issue-bound in their steady state and a double-precision square root is ~25 instructions.
+__device__ __forceinline__ double cl_pair_violation(double hc, double hs)
 {
-    acc[CL_COST] += 0.5 * dt * (w[0] * r0x * r0x + w[1] * r0y * r0y + w[2] * r0s * r0s + w[3] * vy * vy + w[4] * r * r + w[5] * delta * delta);
-    acc[CL_EY2] += r0y * r0y;
+    const double d = fma(hc, hc, fma(hs, hs, -1.0));
+    if (fabs(d) < 0.01) return fabs(d * (0.5 - d * (0.125 - d * 0.0625)));
+    return fabs(sqrt(hc * hc + hs * hs) - 1.0);
 }
 
-// The part known after the plant step: wu = the input's weight, (hc, hs, steer) = the plant's heading pair and steering
-// angle after the step.
-__device__ __forceinline__ void cl_after_step(double *acc, double dt, double wu, double u0, double hc, double hs, double steer,
-                                              double umax, double dmax)
+// One step's contribution to statistic `i` (running value `acc`) from the step's value `v` for that statistic:
+// i < 8 component i of [x0; u0] - yref_0 (squared and added); CL_TRIG_SUM the pair's violation (added); CL_STEPS 1.0;
+// CL_U_MAX |u0|, CL_STEER_MAX |steering angle|, CL_TRIG_MAX the pair's violation, CL_PRED_TRIG_MAX that of the
+// predicted trajectory (maxima).  In the wave-per-scenario kernels lane i < CL_STAT_W carries statistic i in one register.
+__device__ __forceinline__ double cl_step(double acc, int i, double v)
 {
-    const double tv = fabs(sqrt(hc * hc + hs * hs) - 1.0);
-    acc[CL_COST] += 0.5 * dt * wu * u0 * u0;
-    acc[CL_U2] += u0 * u0;
-    acc[CL_TRIG_SUM] += tv;
-    acc[CL_TRIG_MAX] = fmax(acc[CL_TRIG_MAX], tv);
-    acc[CL_BOUND_MAX] = fmax(acc[CL_BOUND_MAX], fmax(fabs(u0) - umax, fabs(steer) - dmax));
-    acc[CL_STEPS] += 1.0;
+    const double add = i == CL_TRIG_SUM ? v : v * v;      // (1.0 squared counts the step)
+    return i >= CL_U_MAX ? fmax(acc, v) : acc + add;
 }
 
-// start of a launch: zeros, or what the previous launch of a chain left
-__device__ __forceinline__ void cl_load(double *acc, const double *rec, bool accumulate)
+// The step's value for statistic `i` from wave-uniform quantities (kernels that do not stage them in LDS): err = this
+// lane's component of [x0; u0] - yref_0 (i < 8), tv the pair's violation, u0 the input, steer the steering angle, pred see above.
+__device__ __forceinline__ double cl_value(int i, double err, double tv, double u0, double steer, double pred)
 {
-#pragma unroll
-    for (int i = 0; i < CL_STAT_W; i++) acc[i] = accumulate ? rec[i] : 0.0;
+    double v = err;
+    v = (i == CL_TRIG_SUM || i == CL_TRIG_MAX) ? tv : v;
+    v = i == CL_STEPS ? 1.0 : v;
+    v = i == CL_U_MAX ? fabs(u0) : v;
+    v = i == CL_STEER_MAX ? fabs(steer) : v;
+    v = i == CL_PRED_TRIG_MAX ? pred : v;
+    return v;
 }
 
 // ---------------------------------------------------------------- EKF linearisation

@@ -335,11 +335,9 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
     constexpr int WS = 2 * WAVE;
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WS] == 1.0;
-    // closed-loop statistics of the scenario (every lane carries the same eight values)
-    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
-    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;
-    double cl[CL_STAT_W] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cl_on) cl_load(cl, a.cl_stat + CL_STAT_W * (size_t)s, a.accumulate != 0);
+    // closed-loop statistics of the scenario
+    const bool cl_on = a.stat_out != nullptr && a.mode != MODE_SOLVE;
+    double cl_acc = (cl_on && a.accumulate && lane < CL_STAT_W) ? a.stat_out[STAT_W * (size_t)s + STAT_CL + lane] : 0.0;   // lane i: statistic i
 
 #pragma unroll 1
     for (int t = 0; t < nsteps; t++) {
@@ -390,7 +388,11 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
             }
         }
         wave_sync();
-        if (cl_on) cl_before_solve(cl, dt, w_cl, s_ref[0], s_ref[N + 1], s_ref[2 * (N + 1)], xh3, xh4, xh5);
+        double cl_err = 0.0;               // lane i < 6: component i of [x0; u0] - yref_0 (the input joins after the solve)
+        if (cl_on) {
+            cl_err = lane < 3 ? s_ref[lane * (N + 1)] : 0.0;
+            cl_err = lane == 3 ? xh3 : lane == 4 ? xh4 : lane == 5 ? xh5 : cl_err;
+        }
 
         // ------------------------------------------------------------ 2. per-stage model
         const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;
@@ -819,9 +821,9 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         }
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
+            if (cl_on) cl_acc = cl_step(cl_acc, lane, cl_value(lane, lane == 6 ? u0 : cl_err, cl_pair_violation(plant[2], plant[3]), u0, plant[7], 0.0));
             plant_rk4_c<10>(plant, u0, dt, pc);
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
-            if (cl_on) cl_after_step(cl, dt, w_cl[6], u0, plant[2], plant[3], plant[7], umax, dmax);
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {
                 double val = plant[0];
@@ -868,14 +870,11 @@ __global__ __launch_bounds__(WAVE) void k_mpc_any(const DevCfg cfg, const SolveA
         if (a.status_out) a.status_out[s] = st_all;
         if (a.iters_out) a.iters_out[s] = it_all;
         if (a.stat_out) {
-            double *so = a.stat_out + 4 * (size_t)s;
+            double *so = a.stat_out + STAT_W * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
-        if (cl_on) {
-#pragma unroll
-            for (int i = 0; i < CL_STAT_W; i++) a.cl_stat[CL_STAT_W * (size_t)s + i] = cl[i];
-        }
     }
+    if (cl_on && lane < CL_STAT_W) a.stat_out[STAT_W * (size_t)s + STAT_CL + lane] = cl_acc;
 }
 
 static size_t any_lds_bytes(int N, int mode)

@@ -11,6 +11,8 @@
 
 namespace mpc {
 
+constexpr int STAT_W = 20;                 // doubles per scenario in SolveArgs::stat_out (4 solver values, CL_STAT_W closed-loop statistics, spare)
+constexpr int STAT_CL = 4;                 // where the closed-loop statistics start in that record
 constexpr int IPM_WARM_DOUBLES = 6 * 128;  // interior-point warm-start record per scenario (see IpmParams); the any-horizon
                                            // kernel keeps [5][128] and its flag at 5 * 128, the register kernels [5][64] and 5 * 64
 
@@ -48,8 +50,9 @@ struct SolveArgs {
     int *status_out, *iters_out;                          // caller's arrays (optional)
     int *status_own, *iters_own;                          // the handle's own copies (always written; mpc_get_stats reads them)
     int *sqp_out;                                         // NL: SQP iterations per scenario (summed over the steps)
-    double *stat_out;                                     // B * 4: mu, residual, constrained, |u0|
-    double *cl_stat;                                      // closed-loop modes: B * CL_STAT_W statistics of the run (mpc_device.hpp), or NULL
+    double *stat_out;                                     // B * STAT_W: mu, residual, constrained, |u0|, then (closed-loop modes) the
+                                                          // CL_STAT_W closed-loop statistics of the run (mpc_device.hpp); one record, so
+                                                          // that the kernels address both through one pointer
     // A long closed-loop run is issued as a chain of launches: `order` (a permutation of 0..B-1, or NULL) maps the
     // wave index to the scenario it advances, so that scenarios that needed many solver iterations in the previous
     // launch start first and share a workgroup; work_out [B] receives this launch's iterations per scenario; with
@@ -132,6 +135,6 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
 // reduction of the per-scenario records into MPC_STATS_LEN doubles; part: STATS_BLOCKS * MPC_STATS_LEN doubles of scratch
 constexpr int STATS_BLOCKS = 256;
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
-                        const int *as2, const double *cl_stat, double *part, double *out);
+                        const int *as2, bool with_closed_loop, const DevCfg &cfg, const double *cost_scen, double *part, double *out);
 
 }  // namespace mpc

@@ -972,8 +972,7 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     const double *lx = a.lin_x ? a.lin_x + (size_t)s * 6 * (N + 1) : nullptr;
     // closed-loop statistics: kept in the scenario's record in memory and updated once per step (eight more values per
     // lane would not fit the registers of this kernel)
-    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
-    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;
+    const bool cl_on = a.stat_out != nullptr && a.mode != MODE_SOLVE;
 
     for (int t = 0; t < nsteps; t++) {
         // ---- 1. start state, references, stage model
@@ -1064,17 +1063,16 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
         }
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
+            if (cl_on) {
+                double *rec = a.stat_out + STAT_W * (size_t)s + STAT_CL;
+                const double err[8] = {r0x, r0y, r0s, xh[3], xh[4], xh[5], u0, 0.0};
+                const double tv = cl_pair_violation(plant[2], plant[3]);
+#pragma unroll
+                for (int i = 0; i < CL_STAT_W; i++)
+                    rec[i] = cl_step((t > 0 || a.accumulate != 0) ? rec[i] : 0.0, i, cl_value(i, i < 8 ? err[i] : 0.0, tv, u0, plant[7], 0.0));
+            }
             plant_rk4_c<10>(plant, u0, dt, pc);                            // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
-            if (cl_on) {
-                double *rec = a.cl_stat + CL_STAT_W * (size_t)s;
-                double acc[CL_STAT_W];
-                cl_load(acc, rec, t > 0 || a.accumulate != 0);
-                cl_before_solve(acc, dt, w_cl, r0x, r0y, r0s, xh[3], xh[4], xh[5]);
-                cl_after_step(acc, dt, w_cl[6], u0, plant[2], plant[3], plant[7], p.umax, p.dmax);
-#pragma unroll
-                for (int i = 0; i < CL_STAT_W; i++) rec[i] = acc[i];
-            }
             if (a.u_hist) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist) {
 #pragma unroll
@@ -1102,7 +1100,7 @@ __global__ __launch_bounds__(WPB * WAVE) void k_mpc_lanes(const DevCfg cfg, cons
     if (a.status_out) a.status_out[s] = st_all;
     if (a.iters_out) a.iters_out[s] = it_all;
     if (a.stat_out) {
-        double *so = a.stat_out + 4 * (size_t)s;
+        double *so = a.stat_out + STAT_W * (size_t)s;
         so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
     }
 }

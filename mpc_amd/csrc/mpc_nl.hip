@@ -163,11 +163,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
     int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     double *Hw = a.Hws + (size_t)s * N * N;
-    // closed-loop statistics of the scenario (every lane carries the same eight values).  The stage cost is the NL
-    // controller's: y = [px, py, cos, sin, vy, r, delta | u] against [x, y, cos, sin, 0, 0, 0 | 0] (NLMPC.py:159-186, 208-212).
-    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
-    double cl[CL_STAT_W] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cl_on) cl_load(cl, a.cl_stat + CL_STAT_W * (size_t)s, a.accumulate != 0);
+    // closed-loop statistics of the scenario (lane i carries statistic i).  The stage cost is the NL controller's:
+    // y = [px, py, cos, sin, vy, r, delta | u] against [x, y, cos, sin, 0, 0, 0 | 0] (NLMPC.py:159-186, 208-212).
+    const bool cl_on = a.stat_out != nullptr && a.mode != MODE_SOLVE;
+    double cl_acc = (cl_on && a.accumulate && lane < CL_STAT_W) ? a.stat_out[STAT_W * (size_t)s + STAT_CL + lane] : 0.0;
 
 #pragma unroll 1
     for (int t = 0; t < nsteps; t++) {
@@ -212,12 +211,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             }
         }
         wave_sync();
+        double cl_err = 0.0;               // lane i < 7: component i of [x0; u0] - yref_0 (the input joins after the solve)
         if (cl_on) {
-            const double r0x = s_ref[0], r0y = s_ref[N + 1], r0c = s_ref[2 * (N + 1)], r0s = s_ref[3 * (N + 1)];
-            const double *w = cfg.w_nl;
-            cl[CL_COST] += 0.5 * dt * (w[0] * r0x * r0x + w[1] * r0y * r0y + w[2] * (1.0 - r0c) * (1.0 - r0c) + w[3] * r0s * r0s +
-                                       w[4] * xh[4] * xh[4] + w[5] * xh[5] * xh[5] + w[6] * xh[6] * xh[6]);
-            cl[CL_EY2] += r0y * r0y;
+            cl_err = lane < 4 ? s_ref[lane * (N + 1)] : 0.0;
+            cl_err = lane == 2 ? 1.0 - cl_err : cl_err;
+            cl_err = lane == 4 ? xh[4] : lane == 5 ? xh[5] : lane == 6 ? xh[6] : cl_err;
         }
         NlCoef cf;          // this lane's stage
         cf.vx = s_p[valid ? lane : 0];
@@ -395,15 +393,14 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         u0 = bcast(U, 0);
         if (a.mode != MODE_SOLVE) {
             const double oldx = plant[0];
-            plant_rk4_c<10>(plant, u0, dt, pc);
-            if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
             if (cl_on) {
-                cl_after_step(cl, dt, cfg.w_nl[7], u0, plant[2], plant[3], plant[7], umax, dmax);
                 // the heading pair over the last roll-out of the solve (lane k: stage k; stage N is one more RK4 step of
                 // the same map): the pair is a free state of this model (skidpad_simulator.py:134)
-                const double pv = wave_max(valid ? fabs(sqrt(keep[2] * keep[2] + keep[3] * keep[3]) - 1.0) : 0.0);
-                cl[CL_PRED_TRIG_MAX] = fmax(cl[CL_PRED_TRIG_MAX], pv);
+                const double pv = wave_max(valid ? cl_pair_violation(keep[2], keep[3]) : 0.0);
+                cl_acc = cl_step(cl_acc, lane, cl_value(lane, lane == 7 ? u0 : cl_err, cl_pair_violation(plant[2], plant[3]), u0, plant[7], pv));
             }
+            plant_rk4_c<10>(plant, u0, dt, pc);
+            if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < 8) {
                 double val = plant[0];
@@ -436,14 +433,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
         if (a.iters_out) a.iters_out[s] = it_all;
         if (a.sqp_out) a.sqp_out[s] = a.accumulate ? a.sqp_out[s] + sqp_tot : sqp_tot;
         if (a.stat_out) {
-            double *so = a.stat_out + 4 * (size_t)s;
+            double *so = a.stat_out + STAT_W * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
-        if (cl_on) {
-#pragma unroll
-            for (int i = 0; i < CL_STAT_W; i++) a.cl_stat[CL_STAT_W * (size_t)s + i] = cl[i];
-        }
     }
+    if (cl_on && lane < CL_STAT_W) a.stat_out[STAT_W * (size_t)s + STAT_CL + lane] = cl_acc;
 }
 
 template <int N>

@@ -182,7 +182,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
 
 // ------------------------------------------------------------------------------------------------
 // LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W], parked plant state and coefficients, and
-// the scenario's closed-loop statistics (PARK_CL.., kept by lane 0)
+// for the closed-loop statistics the step's value for each of them (PARK_CL + i: see cl_step)
 constexpr int PARK_CL = 20;
 constexpr int PARK_W = PARK_CL + CL_STAT_W;
 template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W; }
@@ -213,7 +213,6 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
     double *s_park = wbase + 4 * (N + 1) + N * STAGE_W;   // plant state [10], plant coefficients [7], planner memory and speed while a step's solve runs
-    double *s_cl = s_park + PARK_CL;                      // closed-loop statistics of the scenario (lane 0 only)
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
@@ -288,9 +287,18 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             s_park[15] = pc.c22; s_park[16] = pc.b2;
         }
     }
-    const bool cl_on = a.cl_stat != nullptr && a.mode != MODE_SOLVE;
-    const double *w_cl = a.cost_scen ? a.cost_scen + 43 * (size_t)s : cfg.w;     // diag of W of this scenario
-    if (cl_on && lane == 0) cl_load(s_cl, a.cl_stat + CL_STAT_W * (size_t)s, a.accumulate != 0);
+    // Closed-loop statistics (they live in the scenario's stat_out record: no pointer or flag of their own, which would
+    // be more wave-uniform values alive across the step loop, where the scalar registers are already short).  Lane
+    // i < CL_STAT_W carries statistic i of the scenario: one register for all of them.
+    // Per step the value of every statistic is staged in LDS (the first reference point and the controller's start state
+    // by lane 0 when it parks the plant state, the input and the violation by the whole wave after the solve) and each
+    // lane reads its own: selecting among a dozen wave-uniform values per lane costs several times the instructions.
+    // (The step loop's registers are all taken, scalar ones included: whatever is added here moves the allocation and
+    // shows up as a few more scratch accesses per step -- measured +7% on unconstrained steps, nothing on constrained
+    // ones, for every arrangement tried, running values in LDS instead of a register included.)
+    double cl_acc = 0.0;
+    if (a.mode != MODE_SOLVE && a.accumulate && lane < CL_STAT_W) cl_acc = a.stat_out[STAT_W * (size_t)s + STAT_CL + lane];
+    if (lane < CL_STAT_W) s_park[PARK_CL + lane] = lane == CL_STEPS ? 1.0 : 0.0;
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
@@ -351,9 +359,12 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
 #pragma unroll
             for (int i = 0; i < 10; i++) s_park[i] = plant[i];
             s_park[17] = prevp; s_park[18] = tvel;
+            // [x0; u0] - yref_0 without the input, for the closed-loop statistics (nothing reads it in MODE_SOLVE)
+            s_park[PARK_CL] = s_ref[0]; s_park[PARK_CL + 1] = s_ref[N + 1]; s_park[PARK_CL + 2] = s_ref[2 * (N + 1)];   // (lane 0's own writes)
+            s_park[PARK_CL + 3] = xh3; s_park[PARK_CL + 4] = xh4; s_park[PARK_CL + 5] = xh5;
+
         }
         wave_sync();
-        if (cl_on && lane == 0) cl_before_solve(s_cl, dt, w_cl, s_ref[0], s_ref[N + 1], s_ref[2 * (N + 1)], xh3, xh4, xh5);
 
         // ------------------------------------------------------------ 2. per-stage model (lane k -> stage k)
         const double c3 = (cfg.kind == MPC_KIND_OFL) ? dt * dhat : 0.0;    // OFLMPC2.py:145
@@ -512,9 +523,14 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         if (a.mode != MODE_SOLVE) {
             const PlantCoef pc = {s_park[10], s_park[11], s_park[12], s_park[13], s_park[14], s_park[15], s_park[16]};
             const double oldx = plant[0];
+            {   // closed-loop statistics of this step, from the state the step starts in
+                const double tv = cl_pair_violation(plant[2], plant[3]);
+                s_park[PARK_CL + 6] = u0; s_park[PARK_CL + CL_TRIG_SUM] = tv; s_park[PARK_CL + CL_TRIG_MAX] = tv;
+                s_park[PARK_CL + CL_U_MAX] = fabs(u0); s_park[PARK_CL + CL_STEER_MAX] = fabs(plant[7]);
+                cl_acc = cl_step(cl_acc, lane, s_park[PARK_CL + (lane < CL_STAT_W ? lane : 0)]);
+            }
             plant_rk4_c<10>(plant, u0, dt, pc);                             // skidpad_simulator.py:128
             if (a.mode == MODE_SKIDPAD && plant[0] > SK_CENTER && oldx <= SK_CENTER) lapv += 1;   // :91-93
-            if (cl_on && lane == 0) cl_after_step(s_cl, dt, w_cl[6], u0, plant[2], plant[3], plant[7], umax, dmax);
             if (a.u_hist && lane == 0) a.u_hist[(size_t)t * a.B + s] = u0;
             if (a.x_hist && lane < nxp) {
                 double val = plant[0];
@@ -560,14 +576,11 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         if (a.status_out) a.status_out[s] = st_all;
         if (a.iters_out) a.iters_out[s] = it_all;
         if (a.stat_out) {
-            double *so = a.stat_out + 4 * (size_t)s;
+            double *so = a.stat_out + STAT_W * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
         }
-        if (cl_on) {
-#pragma unroll
-            for (int i = 0; i < CL_STAT_W; i++) a.cl_stat[CL_STAT_W * (size_t)s + i] = s_cl[i];
-        }
     }
+    if (a.mode != MODE_SOLVE && lane < CL_STAT_W) a.stat_out[STAT_W * (size_t)s + STAT_CL + lane] = cl_acc;
     if (!pull) return;
     wave_sync();            // the wave's LDS areas are reused by its next scenario
     }   // work queue

@@ -40,10 +40,16 @@ def test_noalloc_solve_equals_handle_solve(orc64, kind, N, Tf):
         U = torch.full((B, N), float("nan"), dtype=torch.float64, device=dev)
         traj = torch.full((B, N + 1, 7), float("nan"), dtype=torch.float64, device=dev)
         status = torch.full((B,), -1, dtype=torch.int32, device=dev); iters = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        rc = lib.mpc_solve_only_noalloc(C.byref(ctl.solver.cfg), _dev.stream_ptr(dev), B, _dev.ptr(x0d), _dev.ptr(wpd), _dev.ptr(pd),
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        cfg_nob = C.pointer(type(ctl.solver.cfg).from_buffer_copy(ctl.solver.cfg))
+        cfg_nob.contents.B = 0                                       # the handle's capacity is not read by this entry point
+        rc = lib.mpc_solve_only_noalloc(cfg_nob, _dev.stream_ptr(dev), B, _dev.ptr(x0d), _dev.ptr(wpd), _dev.ptr(pd),
                                         _dev.ptr(dhd), _dev.ptr(U), _dev.ptr(traj), _dev.ptr(status), _dev.ptr(iters))
         _lib.check(rc, None, "mpc_solve_only_noalloc")
         torch.cuda.synchronize()
+        if B != 64:                                                  # past the first call's one-time address look-up:
+            assert torch.cuda.mem_get_info(dev)[0] == free_before    # the device's free memory did not move
         assert torch.equal(U, U_ref) and torch.equal(traj, traj_ref)
         assert torch.equal(status, st_ref) and torch.equal(iters, it_ref)
         assert int((iters > 0).sum()) >= 1                                       # the interior point ran ...
