@@ -36,6 +36,58 @@ def test_c1_full_skidpad_run_matches_checker(orc64):
     assert abs(np.hypot(xs[:, 2], xs[:, 3]) - 1).max() < 1e-6  # the heading vector stays normalised (skidpad_simulator.py:134)
 
 
+def _full_run(orc, model, N, Tf, nsteps=3400, ctl_kw=None, cfg_kw=None):
+    """The checker's run from the default start (skidpad_simulator.py:50-60), recorded every 100 steps with the
+    controller's memory (LPV prev_x / prev_u, NL iterate) carried from block to block, and the library's fused run."""
+    import torch
+    from oracle import oracle as O
+    from mpc_amd.batched import SkidpadBatch
+    start = np.array([[15.0, 0.1, 1.0, 0.0, 8.0, 0.0, 0.0, 0.0]])
+    cfg = O.make_cfg(model, N, Tf, **(cfg_kw or {}))
+    ref = start.copy(); laps = np.zeros(1, np.int32); pp = np.zeros(1)
+    lx = np.zeros((1, 6, N + 1)); lu = np.zeros((1, N))
+    marks = []
+    for blk in range(nsteps // 100):
+        orc.skidpad_run(cfg, ref, laps, pp, 8.0, 100, record=False, lin_x=lx, lin_u=lu)
+        marks.append((ref[0].copy(), int(laps[0])))
+    sim = SkidpadBatch(N, Tf, start, model=model, **(ctl_kw or {}))
+    xs, us = sim.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    return sim, xs.cpu().numpy()[:, 0], us.cpu().numpy()[:, 0], marks
+
+
+def _c1_gates(sim, xs, marks, laps_expected=5):
+    assert (sim.status.cpu().numpy() == 0).all()
+    worst_pos = worst_yaw = 0.0
+    for blk, (xr, lap) in enumerate(marks):
+        x = xs[100 * (blk + 1) - 1]
+        worst_pos = max(worst_pos, np.hypot(x[0] - xr[0], x[1] - xr[1]))
+        dyaw = np.arctan2(x[3], x[2]) - np.arctan2(xr[3], xr[2])
+        worst_yaw = max(worst_yaw, abs((dyaw + np.pi) % (2 * np.pi) - np.pi))
+    assert worst_pos <= 1e-3 and worst_yaw <= 1e-4, (worst_pos, worst_yaw)
+    assert int(sim.lap.item()) == marks[-1][1] == laps_expected
+    assert abs(np.hypot(xs[:, 2], xs[:, 3]) - 1).max() < 1e-6
+    return worst_pos, worst_yaw
+
+
+@pytest.mark.parametrize("layout", ["wave", "lane"])
+def test_default_controller_full_skidpad_run_matches_checker(orc64, layout):
+    """The reference's default controller, SkidpadSimulator(model="LPV") (skidpad_simulator.py:24) at its canonical
+    N = 80, Tf = 0.8 (plot_generator.py:604): the whole skidpad, through every circle change and lap bump, in both solver
+    layouts, with the C1 gates (1e-3 m, 1e-4 rad, equal lap counts)."""
+    sim, xs, us, marks = _full_run(orc64, "LPV", 80, 0.8, ctl_kw={"solver_layout": layout})
+    _c1_gates(sim, xs, marks)
+    assert np.abs(us).max() <= 0.9 + 1e-9 and np.abs(xs[:, 7]).max() <= 0.3 + 1e-6
+
+
+def test_nonlinear_controller_full_skidpad_run_matches_checker(orc64):
+    """SkidpadSimulator(model="NL"), N = 50: the non-convex programme's local solution depends on the iterate history,
+    so the run also shows that library and checker stay on the same branch through the whole figure of eight."""
+    kw = dict(sqp_tol=1e-10, sqp_max_iter=50)
+    sim, xs, us, marks = _full_run(orc64, "NL", 50, 0.5, ctl_kw=kw, cfg_kw=dict(sqp_tol=1e-11, sqp_max_iter=50))
+    _c1_gates(sim, xs, marks)
+
+
 @pytest.mark.parametrize("kind", ["L", "OFL"])
 def test_sampled_solutions_satisfy_kkt(orc64, kind):
     """Independent of the checker's solver: stationarity of H U + g over the active set by non-negative least squares,

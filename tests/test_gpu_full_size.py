@@ -104,3 +104,17 @@ def test_full_batch_output_feedback_scenarios_are_independent():
     assert bool(torch.isfinite(xs).all()) and bool(torch.isfinite(es).all())
     # status 4 marks steps whose estimated steering angle lay outside the bound (the bound is widened there); no other flag
     assert set(np.unique(full.status.cpu().numpy())) <= {0, 4}
+    # eight scenarios of the full batch followed by the checker's loop (simulator.py:206-281) through all 300 steps, with
+    # the same noise samples: inputs at the closed-loop bar, plant states and estimates to 1e-6
+    from oracle import oracle as O
+    orc = O.Oracle("f64")
+    pick = idx[:8]
+    cfg = O.make_cfg("OFL", N, Tf)
+    x = true0[pick].copy(); e = est0[pick].copy(); P = np.tile(np.diag(O.EKF_P0_DIAG), (8, 1, 1))
+    u_ref, x_ref, e_ref, st_ref, _ = orc.ofl_run(cfg, x, e, P, 15.0, nsteps, noise=np.ascontiguousarray(noise[:, pick]))
+    u_gpu = us[:, tidx[:8]].cpu().numpy(); x_gpu = xs[:, tidx[:8]].cpu().numpy(); e_gpu = es[:, tidx[:8]].cpu().numpy()
+    err = np.abs(u_gpu - u_ref)
+    assert (err <= _utol(u_ref)).all(), (np.unravel_index(np.argmax(err / _utol(u_ref)), err.shape), err.max())
+    np.testing.assert_allclose(x_gpu, x_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(e_gpu, e_ref, rtol=0, atol=1e-6)
+    assert (full.status.cpu().numpy()[pick] == st_ref).all()
