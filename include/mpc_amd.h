@@ -157,6 +157,21 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
                    const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out,
                    int *status_out, int *iters_out);
 
+/* optimize() with HOST arrays in and out and a blocking return: the calling convention of the reference's own
+ * LOcp / LPVOcp / OFLOcp / NLOcp.optimize (numpy in, numpy out; LMPC2.py:296-347), for one controller or a handful
+ * (B <= min(cfg.B, MPC_HOST_MAX_B)).  Arguments as mpc_solve_only, but every pointer is host memory; lin_x / lin_u are
+ * read and updated in the caller's arrays.  The library packs the arguments into a block of pinned host memory that the
+ * GPU addresses directly (allocated by the first call on a handle, none later): one kernel launch and one stream
+ * synchronisation per call, no copy commands -- the latency a controller that solves one problem per control period sees. */
+#define MPC_HOST_MAX_B 64
+int mpc_optimize_host(mpc_handle *h, void *stream, int B, const double *x0, const double *wp, const double *p,
+                      const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out, int *status_out,
+                      int *iters_out);
+
+/* LPVOcp.optimize(..., lin_mode) (LPVMPC.py:254-297): 0 = "reference", 1 = "prev_iter", for the following solves of an
+ * LPV handle (the creation-time value is mpc_config.lpv_lin_prev). */
+int mpc_set_lpv_lin_mode(mpc_handle *h, int lin_prev);
+
 /* mpc_solve_only for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc): no handle, no workspace argument, no hipMalloc / hipFree inside.  It has no counterpart in
  * the reference.  The condensed problems live in a static device array of the library (2.1 MB per GPU, held until the

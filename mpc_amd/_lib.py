@@ -48,6 +48,8 @@ _SIGS = {
     "mpc_set_cost_weights": ([_vp, _vp], C.c_int),
     "mpc_condense_fixed": ([_vp, _vp, C.c_double, C.c_int], C.c_int),
     "mpc_solve_only": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
+    "mpc_optimize_host": ([_vp, _vp, C.c_int] + [_vp] * 10, C.c_int),
+    "mpc_set_lpv_lin_mode": ([_vp, C.c_int], C.c_int),
     "mpc_solve_only_noalloc": ([C.POINTER(MpcConfig), _vp, C.c_int] + [_vp] * 8, C.c_int),
     "mpc_closed_loop_step": ([_vp, _vp, C.c_int, C.c_int] + [_vp] * 12, C.c_int),
     "mpc_closed_loop_run": ([_vp, _vp, C.c_int, C.c_int, C.c_int] + [_vp] * 14, C.c_int),

@@ -128,6 +128,8 @@ class _CondensedMpc:
                 self.set_terminal_set(terminal_set)
         self.metrics = {"runtime": []}
         self._bufs = {}
+        self._auto_cache = self.batch == 1          # optimize() of a single controller (batched users call condense_fixed themselves)
+        self._cache_candidate = self._cached_vx = None
 
     # ---- set-up -----------------------------------------------------------------------------
     def get_tyre_stiffness(self) -> tuple[float, float]:
@@ -267,10 +269,26 @@ class _CondensedMpc:
         if len(pv) < self.N + 1:
             pfull[self.N] = pv[self.N - 1]          # the stage-N parameter is never used (LMPC2.py:301-303)
         dh = None if d_hat is None else np.array([float(d_hat)])
-        U, traj, status, iters = self.solve_batched(x0[None, :7], wp[None], pfull[None], dh, lin_x, lin_u)
-        U = U.cpu().numpy()[0]; traj = traj.cpu().numpy()[0]
-        st = int(status.item())
-        self.last_iterations = int(iters.item())
+        if self.kind in ("L", "OFL") and self._auto_cache:
+            # The planners hand the controller one constant speed (path_planning.py:238-240): the second call in a row
+            # with the same constant profile condenses the horizon once for that speed (mpc_condense_fixed, non-exclusive:
+            # any other profile still condenses its own problem), and the following calls are one cached affine map.
+            v = pfull[0]
+            if (pfull[: self.N] == v).all():
+                if v == self._cache_candidate and v != self._cached_vx:
+                    self.condense_fixed(v, exclusive=False)
+                    self._cached_vx = v
+                self._cache_candidate = v
+        # host arrays in, host arrays out: one launch and one synchronisation (mpc_optimize_host); lin_x / lin_u are
+        # C-contiguous float64 host arrays, updated in place
+        x0c = np.ascontiguousarray(x0[:7]); wp = np.ascontiguousarray(wp)
+        U = np.empty(self.N); traj = np.empty((self.N + 1, 7)); st_it = np.zeros(2, dtype=np.int32)
+        hp = lambda a: None if a is None else a.ctypes.data
+        rc = self.solver._lib.mpc_optimize_host(self.solver.h, _dev.stream_ptr(self.device), 1, hp(x0c), hp(wp), hp(pfull), hp(dh),
+                                                hp(lin_x), hp(lin_u), hp(U), hp(traj), st_it.ctypes.data, st_it.ctypes.data + 4)
+        _lib.check(rc, self.solver.h, "mpc_optimize_host")
+        st = int(st_it[0])
+        self.last_iterations = int(st_it[1])
         self.metrics["runtime"].append(time.perf_counter() - t0)
         if st == 2:
             log.warning("interior-point iteration cap reached (status 2)")
@@ -312,6 +330,7 @@ class _CondensedMpc:
         """Cache the condensed problem for a constant speed profile (None switches the cache off).  With
         `exclusive` the caller promises that every scenario runs at vx (status 3 flags a broken promise)."""
         v = float("nan") if vx is None else float(vx)
+        self._cached_vx = None if vx is None else float(vx)
         rc = self.solver._lib.mpc_condense_fixed(self.solver.h, _dev.stream_ptr(self.device), v, int(bool(exclusive)))
         _lib.check(rc, self.solver.h, "mpc_condense_fixed")
 
@@ -388,15 +407,14 @@ class LPVOcp(_CondensedMpc):
         if lin_mode not in ("reference", "prev_iter"):
             raise ValueError(f"unknown lin_mode {lin_mode!r}")
         if lin_mode != self._lin_mode:
-            # the linearisation rule is part of the solver definition: rebuild the handle
             self._lin_mode = lin_mode
-            cfg = self._make_config(); cfg.lpv_lin_prev = 1 if lin_mode == "prev_iter" else 0
-            self.solver.close(); self.solver = SolverHandle(cfg)
-        lin_x = _dev.f64(self.prev_x[None], self.device)
-        lin_u = _dev.f64(np.asarray(self.prev_u)[:, : self.N][None, 0], self.device)
+            _lib.check(self.solver._lib.mpc_set_lpv_lin_mode(self.solver.h, 1 if lin_mode == "prev_iter" else 0), self.solver.h,
+                       "mpc_set_lpv_lin_mode")
+        lin_x = np.ascontiguousarray(self.prev_x, dtype=np.float64).copy()
+        lin_u = np.ascontiguousarray(np.asarray(self.prev_u, dtype=np.float64)[0, : self.N]).copy()
         out = self._optimize_one(x0, waypoints, p, lin_x=lin_x, lin_u=lin_u)
-        self.prev_x = lin_x.cpu().numpy()[0]
-        self.prev_u = lin_u.cpu().numpy()
+        self.prev_x = lin_x
+        self.prev_u = lin_u[None, :]
         return out
 
 
@@ -417,6 +435,7 @@ class NLOcp(_CondensedMpc):
         super().__init__(N, Tf, True, debug, **kw)
         self._iterate = None if self.device is None else torch.zeros((self.batch, self.N), dtype=torch.float64,
                                                                      device=self.device)
+        self._iterate_host = np.zeros(self.N)        # the iterate optimize() carries (solve_batched keeps its own on the device)
 
     def _cost_matrices(self):
         Q = np.array([0, 1e5, 1e-10, 1e0, 0, 1e0, 1e0])                              # NLMPC.py:174-179
@@ -455,6 +474,7 @@ class NLOcp(_CondensedMpc):
 
     def reset_iterate(self):
         self._iterate.zero_()
+        self._iterate_host[:] = 0.0
 
     def solve_batched(self, x0, waypoints, p, d_hat=None, lin_x=None, lin_u=None, want_trajectory=True):
         """Batched optimize(); `lin_u` (B,N) is the SQP iterate, read and updated in place (default: the iterate this
@@ -464,4 +484,4 @@ class NLOcp(_CondensedMpc):
         return super().solve_batched(x0, waypoints, p, None, None, lin_u, want_trajectory)
 
     def optimize(self, x0, waypoints, p):
-        return self._optimize_one(x0, waypoints, p)
+        return self._optimize_one(x0, waypoints, p, lin_u=self._iterate_host)

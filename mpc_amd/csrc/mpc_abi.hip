@@ -37,6 +37,9 @@ struct mpc_handle {
     int sh_mask = 0;
     bool sh_on = false, sh_exclusive = false;
     int last_B = 0;
+    // staging of mpc_optimize_host: one block of pinned host memory that the GPU addresses directly (inputs, the
+    // controller's carried memory, outputs), allocated by the first call
+    double *host_stage = nullptr, *host_stage_dev = nullptr;
     std::string err;
 };
 
@@ -188,6 +191,7 @@ void mpc_destroy(mpc_handle *h)
     (void)hipFree(h->stats_out); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T); (void)hipFree(h->as2);
     (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
+    if (h->host_stage) (void)hipHostFree(h->host_stage);
     delete h;
 }
 
@@ -393,6 +397,74 @@ int mpc_solve_only(mpc_handle *h, void *stream, int B, const double *x0, const d
     attach_cache(h, a);
     h->last_B = B; h->cl_valid = false;
     HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
+    return MPC_OK;
+}
+
+// optimize() with host arrays in and out (the reference's own calling convention: numpy in, numpy out, blocking).
+// The arguments are packed into a block of pinned host memory that the kernels read and write in place over the bus (a
+// few KB per scenario): one kernel launch and one stream synchronisation per call, no copy commands.
+static size_t host_stage_doubles(int N, int B)
+{
+    const size_t n1 = (size_t)N + 1, b = (size_t)B;
+    return b * (7 + 4 * n1 + n1 + 1 + 6 * n1 + (size_t)N + (size_t)N + 7 * n1 + 1);       // the last 1: status and iterations (two ints)
+}
+
+int mpc_optimize_host(mpc_handle *h, void *stream, int B, const double *x0, const double *wp, const double *p,
+                      const double *d_hat, double *lin_x, double *lin_u, double *U_out, double *traj_out, int *status_out,
+                      int *iters_out)
+{
+    if (!h) return MPC_EINVAL;
+    const int cap = h->cfg.B < MPC_HOST_MAX_B ? h->cfg.B : MPC_HOST_MAX_B;
+    if (B < 1 || B > cap) return fail(h, MPC_EINVAL, "mpc_optimize_host: B outside 1..min(cfg.B, MPC_HOST_MAX_B)");
+    ON_HANDLE_DEVICE(h);
+    if (!x0 || !wp || !p || !U_out) return fail(h, MPC_EINVAL, "mpc_optimize_host: x0, wp, p and U_out are required");
+    const int kind = h->cfg.kind, N = h->cfg.N;
+    if (kind == MPC_KIND_LPV && (!lin_x || !lin_u)) return fail(h, MPC_EINVAL, "mpc_optimize_host: LPV needs lin_x and lin_u");
+    if (kind == MPC_KIND_NL && !lin_u) return fail(h, MPC_EINVAL, "mpc_optimize_host: NL needs lin_u (the SQP iterate)");
+    if (!h->host_stage) {
+        HIP_TRY(h, hipHostMalloc((void **)&h->host_stage, host_stage_doubles(N, cap) * sizeof(double), hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer((void **)&h->host_stage_dev, h->host_stage, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h->host_stage); h->host_stage = nullptr; return hip_fail(h, e, "mpc_optimize_host: hipHostGetDevicePointer"); }
+    }
+    const size_t n1 = (size_t)N + 1, b = (size_t)B;
+    // segments, in doubles from the start of the block (packed for this call's B)
+    const size_t o_x0 = 0, o_wp = o_x0 + 7 * b, o_p = o_wp + 4 * n1 * b, o_dh = o_p + n1 * b, o_lx = o_dh + b, o_lu = o_lx + 6 * n1 * b,
+                 o_U = o_lu + (size_t)N * b, o_tr = o_U + (size_t)N * b, o_int = o_tr + 7 * n1 * b;
+    double *hs = h->host_stage, *ds = h->host_stage_dev;
+    memcpy(hs + o_x0, x0, 7 * b * sizeof(double));
+    memcpy(hs + o_wp, wp, 4 * n1 * b * sizeof(double));
+    memcpy(hs + o_p, p, n1 * b * sizeof(double));
+    if (d_hat) memcpy(hs + o_dh, d_hat, b * sizeof(double));
+    if (lin_x) memcpy(hs + o_lx, lin_x, 6 * n1 * b * sizeof(double));
+    if (lin_u) memcpy(hs + o_lu, lin_u, (size_t)N * b * sizeof(double));
+    mpc::SolveArgs a = {};
+    a.mode = mpc::MODE_SOLVE; a.B = B; a.nsteps = 1; a.nx_plant = 8;
+    a.x0 = ds + o_x0; a.wp = ds + o_wp; a.p = ds + o_p; a.d_hat = d_hat ? ds + o_dh : nullptr;
+    a.lin_x = lin_x ? ds + o_lx : nullptr; a.lin_u = lin_u ? ds + o_lu : nullptr;
+    a.mp_scen = h->mp_scen; a.cost_scen = h->cost_scen; a.Hws = h->Hws; a.ipm_ws = h->ipm_ws;
+    a.U_out = ds + o_U; a.traj_out = traj_out ? ds + o_tr : nullptr;
+    a.status_out = reinterpret_cast<int *>(ds + o_int); a.iters_out = a.status_out + B;
+    a.status_own = h->status; a.iters_own = h->iters; a.term_m = h->term_m; a.term_C = h->term_C; a.px_free = h->px_free;
+    a.stat_out = h->stat;
+    attach_cache(h, a);
+    h->last_B = B; h->cl_valid = false;
+    HIP_TRY(h, launch_for_kind(h, a, (hipStream_t)stream));
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    memcpy(U_out, hs + o_U, (size_t)N * b * sizeof(double));
+    if (traj_out) memcpy(traj_out, hs + o_tr, 7 * n1 * b * sizeof(double));
+    if (lin_x) memcpy(lin_x, hs + o_lx, 6 * n1 * b * sizeof(double));
+    if (lin_u) memcpy(lin_u, hs + o_lu, (size_t)N * b * sizeof(double));
+    const int *ints = reinterpret_cast<const int *>(hs + o_int);
+    if (status_out) memcpy(status_out, ints, b * sizeof(int));
+    if (iters_out) memcpy(iters_out, ints + B, b * sizeof(int));
+    return MPC_OK;
+}
+
+int mpc_set_lpv_lin_mode(mpc_handle *h, int lin_prev)
+{
+    if (!h) return MPC_EINVAL;
+    if (h->cfg.kind != MPC_KIND_LPV) return fail(h, MPC_EINVAL, "mpc_set_lpv_lin_mode: handle is not an LPV controller");
+    h->cfg.lpv_lin_prev = lin_prev != 0; h->dev.lpv_lin_prev = h->cfg.lpv_lin_prev;
     return MPC_OK;
 }
 

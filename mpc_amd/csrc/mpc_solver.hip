@@ -494,16 +494,24 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 }
             }
             if (a.traj_out) {
-                // 7-column form [x, y, cos(psi), sin(psi), vy, r, delta] (LMPC2.py:337-345)
+                // 7-column form [x, y, cos(psi), sin(psi), vy, r, delta] (LMPC2.py:337-345).  The rows go through LDS (the
+                // stage table is dead once the roll-out is done) and leave as consecutive doubles: a lane writing its own
+                // row touches seven cache lines per store instruction, which over the bus (mpc_optimize_host writes
+                // straight into host memory) is seven times the transactions.
+                static_assert(N * STAGE_W >= 7 * (N + 1), "the stage table holds the trajectory");
+                wave_sync();
                 if (valid) {
-                    double *o = a.traj_out + ((size_t)s * (N + 1) + lane) * 7;
+                    double *o = s_stage + lane * 7;
                     o[0] = keep[0]; o[1] = keep[1]; o[2] = cos(keep[2]); o[3] = sin(keep[2]); o[4] = keep[3];
                     o[5] = keep[4]; o[6] = keep[5];
                 }
                 if (lane == 0) {
-                    double *o = a.traj_out + ((size_t)s * (N + 1) + N) * 7;
+                    double *o = s_stage + N * 7;
                     o[0] = x[0]; o[1] = x[1]; o[2] = cos(x[2]); o[3] = sin(x[2]); o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
                 }
+                wave_sync();
+                double *to = a.traj_out + (size_t)s * (N + 1) * 7;
+                for (int e = lane; e < 7 * (N + 1); e += WAVE) to[e] = s_stage[e];
             }
             if (cfg.kind == MPC_KIND_LPV) {
                 // prev_x <- solver states (6 x (N+1)), prev_u <- inputs (LPVMPC.py:313-327)
