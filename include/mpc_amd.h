@@ -104,6 +104,20 @@ typedef struct mpc_config {
                           * to the interior point.  Both give the unique minimiser (they agree to the solver tolerances,
                           * not bit for bit).  MPC_QP_INTERIOR_POINT: interior point only.  MPC_QP_ACTIVE_SET: the same as
                           * AUTO (kept for callers written when mpc_ofl_closed_loop_run needed it to use the method) */
+    int emulate_acados;  /* 0 (default): every solve returns the unique minimiser of the problem the reference poses.
+                          * 1 (kinds L, OFL, LPV at the horizons 10, 20, 30, 40, 50, 64; wave layout): the solve goes
+                          * through what the reference's solver options (LMPC2.py:262-288: SQP, EXACT Hessian,
+                          * regularize_method MIRROR, tol 1e-4, iterate kept between calls) do to that problem instead:
+                          * every cost weight below reg_epsilon (the unweighted states px, vy, r) is lifted to
+                          * reg_epsilon, which makes one SQP step the minimiser of the problem plus
+                          * 1/2 reg_epsilon |x_i - x_prev,i|^2 on those states about the iterate kept from the previous
+                          * step; full steps are repeated until reg_epsilon * max |x - x_prev| <= sqp_kkt_tol (the
+                          * stationarity residual the regularisation leaves; at most sqp_max_iter steps, status 1 beyond),
+                          * and the iterate stays in the handle for the next call (mpc_reset_warm_start zeroes it, as a
+                          * new solver object starts).  A restatement of published behaviour, as unpinned as the rest of
+                          * the QP parity: acados itself cannot run beside it.  The fixed-model cache is not used. */
+    double reg_epsilon;  /* emulate_acados: acados' reg_epsilon (default 1e-4)                                   */
+    double sqp_kkt_tol;  /* emulate_acados: the reference's tolerance on the KKT residual (default 1e-4)           */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
@@ -285,8 +299,10 @@ int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, cons
  * like its terminal cost reference).  This is the constraint the reference prepares and leaves commented out
  * (LMPC2.py:212-218: con_h_expr_e = C (x[1:] - x_ref), uh_e = 1, lh_e = -1e7; C from
  * stability.py:93-112 reconstruct_control_amissible_invariant_set).  C_host: m rows of 5 doubles, host memory, copied;
- * m = 0 removes the set.  General rows are handled by the stage-wise solver only: the handle must have been created
- * with solver_layout = MPC_LAYOUT_LANE (MPC_EINVAL otherwise).  Synchronises the device, resizes the handle's workspace
+ * m = 0 removes the set.  General rows are handled by the stage-wise solver: a handle created with MPC_LAYOUT_AUTO moves
+ * to the lane-per-scenario layout with the first set it is given (and stays there; the fixed-model cache and
+ * mpc_ofl_closed_loop_run belong to the wave layout and are then off), one created with MPC_LAYOUT_LANE is there already,
+ * one created with MPC_LAYOUT_WAVE refuses the rows (MPC_EINVAL).  Synchronises the device, resizes the handle's workspace
  * and forgets the warm-start records.  A problem whose terminal set cannot be reached within the input bounds has no
  * minimiser: such solves end with status 2. */
 int mpc_set_terminal_set(mpc_handle *h, int m, const double *C_host);

@@ -25,6 +25,7 @@ class MpcConfig(C.Structure):
         ("w_nl", C.c_double * 8), ("we_nl", C.c_double * 7), ("eps_nl", C.c_double), ("sqp_tol", C.c_double),
         ("sqp_max_iter", C.c_int), ("ipm_cold_start", C.c_int), ("step_ramp_length", C.c_double),
         ("solver_layout", C.c_int), ("qp_method", C.c_int),
+        ("emulate_acados", C.c_int), ("reg_epsilon", C.c_double), ("sqp_kkt_tol", C.c_double),
     ]
 
 

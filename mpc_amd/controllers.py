@@ -78,7 +78,8 @@ class _CondensedMpc:
     def __init__(self, N: int, Tf: float, discrete: bool = True, debug: bool = False, *, params=None, device=None,
                  batch: int = 1, tol_mu: float = 1e-15, tol_res: float = 1e-12, max_iter: int = 80,
                  ipm_warm_start: bool = True, step_ramp_length: float = 0.0, solver_layout: str = "auto",
-                 terminal_set=None, qp_method: str = "auto", _host_only: bool = False):
+                 terminal_set=None, qp_method: str = "auto", emulate_acados: bool = False, reg_epsilon: float = 1e-4,
+                 sqp_kkt_tol: float = 1e-4, sqp_max_iter: int = 200, _host_only: bool = False):
         if not discrete and self.kind != "LPV":
             # The reference's constructors do not get past their own stability analysis with discrete=False: that
             # branch keeps the 6x6 continuous-time A next to the 5x5 Q (LMPC2.py:370-382,406,411; OFLMPC2.py:389-402,
@@ -116,6 +117,9 @@ class _CondensedMpc:
         # "auto": constrained solves of the fixed-model path go through the active-set method first (interior point where
         # it does not end at the minimiser); "interior_point": interior point only; "active_set": the same as "auto"
         self._qp_method = _lib.QP_METHOD[qp_method]
+        # emulate_acados: not the minimiser of the posed problem but what the reference's solver options make of it (MIRROR
+        # regularisation about the iterate kept between calls, SQP steps until the KKT tolerance; LMPC2.py:262-288)
+        self._emulate = (bool(emulate_acados), float(reg_epsilon), float(sqp_kkt_tol), int(sqp_max_iter))
         if terminal_set is not None and solver_layout == "auto":
             self._layout = _lib.LAYOUT["lane"]          # general terminal rows are handled by the stage-wise solver
         if _host_only:                      # set-up arithmetic only (used by the CPU tests); no solve is possible
@@ -128,7 +132,7 @@ class _CondensedMpc:
                 self.set_terminal_set(terminal_set)
         self.metrics = {"runtime": []}
         self._bufs = {}
-        self._auto_cache = self.batch == 1          # optimize() of a single controller (batched users call condense_fixed themselves)
+        self._auto_cache = self.batch == 1 and not emulate_acados          # optimize() of a single controller (batched users call condense_fixed themselves)
         self._cache_candidate = self._cached_vx = None
 
     # ---- set-up -----------------------------------------------------------------------------
@@ -184,6 +188,9 @@ class _CondensedMpc:
         cfg.step_ramp_length = self._step_ramp
         cfg.solver_layout = self._layout
         cfg.qp_method = self._qp_method
+        cfg.emulate_acados, cfg.reg_epsilon, cfg.sqp_kkt_tol, sqp_max = self._emulate
+        if cfg.emulate_acados:
+            cfg.sqp_max_iter = sqp_max                  # LMPC2.py:281 nlp_solver_max_iter = 200
         return cfg
 
     def stability(self):
@@ -218,12 +225,16 @@ class _CondensedMpc:
 
     def set_terminal_set(self, C):
         """Adds the terminal constraint C (x_N[1:] - x_ref) <= 1 the reference leaves commented out (LMPC2.py:212-218) to
-        every following solve; C (m, 5) over (py, psi, vy, r, delta), None removes it.  Needs solver_layout "lane"."""
+        every following solve; C (m, 5) over (py, psi, vy, r, delta), None removes it.  A controller created with
+        solver_layout "auto" moves to the lane-per-scenario solver with its first set; "wave" refuses."""
         C = np.zeros((0, 5)) if C is None else np.ascontiguousarray(C, dtype=np.float64)
         if C.ndim != 2 or C.shape[1] != 5:
             raise ValueError("terminal set: rows of 5 coefficients over (py, psi, vy, r, delta)")
         rc = self.solver._lib.mpc_set_terminal_set(self.solver.h, int(C.shape[0]), _lib.hptr(C))
         _lib.check(rc, self.solver.h, "mpc_set_terminal_set")
+        if C.shape[0]:
+            self._cached_vx = self._cache_candidate = None       # the lane layout has no fixed-model cache
+            self._auto_cache = False
 
     # ---- per step -----------------------------------------------------------------------------
     def waypoints_to_references(self, waypoints: np.ndarray) -> np.ndarray:

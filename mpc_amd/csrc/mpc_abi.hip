@@ -29,6 +29,7 @@ struct mpc_handle {
     double *stats_out = nullptr; // device result of the statistics reduction (MPC_STATS_LEN) and its per-workgroup partial vectors
     bool cl_valid = false;       // the last call was a closed-loop call (the closed-loop part of `stat` belongs to it)
     double *sh_H = nullptr, *sh_Kref = nullptr, *sh_Kx = nullptr;   // fixed-model cache (mpc_condense_fixed)
+    double *sqp_x = nullptr;     // emulate_acados: SQP iterates [B][6][N+1] (zero = a new solver object)
     double *sh_T = nullptr;      // table of the active-set solve (part of the cache; NULL with qp_method = interior point)
     double sh_T_resid = 0.0;     // largest entry of |H inv(H) - I| of that table (checked when it is built)
     bool sh_T_ok = false;        // the table is accurate enough for the active-set solve to certify its points with
@@ -112,6 +113,12 @@ static const char *check_config(const mpc_config *cfg, bool with_workspace = tru
     if (cfg->solver_layout == MPC_LAYOUT_LANE && cfg->kind == MPC_KIND_NL) return "the NL controller has no lane-per-scenario kernel";
     if (cfg->qp_method < MPC_QP_AUTO || cfg->qp_method > MPC_QP_ACTIVE_SET) return "unknown qp_method";
     if (!(cfg->max_rate > 0.0) || !(cfg->max_steering > 0.0)) return "max_rate and max_steering must be positive";
+    if (cfg->emulate_acados) {
+        if (cfg->kind == MPC_KIND_NL) return "emulate_acados: the NL controller already runs the SQP iteration of its solver";
+        if (!mpc::horizon_templated(cfg->N)) return "emulate_acados: horizons 10, 20, 30, 40, 50, 64 only";
+        if (cfg->solver_layout == MPC_LAYOUT_LANE) return "emulate_acados: wave layout only";
+        if (cfg->reg_epsilon < 0.0 || cfg->sqp_kkt_tol < 0.0) return "emulate_acados: reg_epsilon and sqp_kkt_tol must not be negative";
+    }
     return nullptr;
 }
 
@@ -122,6 +129,7 @@ static void fill_devcfg(const mpc_config *cfg, mpc::DevCfg &d)
     d.tol_mu = cfg->tol_mu > 0 ? cfg->tol_mu : 1e-15; d.tol_res = cfg->tol_res > 0 ? cfg->tol_res : 1e-12;
     memcpy(d.mp, cfg->mp, sizeof d.mp); memcpy(d.w, cfg->w, sizeof d.w); memcpy(d.We, cfg->We, sizeof d.We);
     memcpy(d.w_nl, cfg->w_nl, sizeof d.w_nl); memcpy(d.we_nl, cfg->we_nl, sizeof d.we_nl);
+    d.reg_eps = cfg->reg_epsilon > 0 ? cfg->reg_epsilon : 1e-4; d.kkt_tol = cfg->sqp_kkt_tol > 0 ? cfg->sqp_kkt_tol : 1e-4;
     d.eps_nl = cfg->eps_nl; d.sqp_tol = cfg->sqp_tol > 0 ? cfg->sqp_tol : 1e-9; d.sqp_max_iter = cfg->sqp_max_iter > 0 ? cfg->sqp_max_iter : 30;
 }
 
@@ -148,7 +156,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     // scenarios, 2.7 against 0.8 M at 8192; below 2048 scenarios a wavefront per scenario has the shorter step).  At the
     // instantiated horizons the wave kernels win at every batch size (LPV at N = 50: 6.9 against 4.4 M at 8192).
     h->lanes = cfg->solver_layout == MPC_LAYOUT_LANE ||
-               (cfg->solver_layout == MPC_LAYOUT_AUTO && (cfg->kind == MPC_KIND_LPV || cfg->kind == MPC_KIND_L) &&
+               (cfg->solver_layout == MPC_LAYOUT_AUTO && !cfg->emulate_acados && (cfg->kind == MPC_KIND_LPV || cfg->kind == MPC_KIND_L) &&
                 !mpc::horizon_templated(cfg->N) && cfg->B >= 2048);
     fill_devcfg(cfg, h->dev);
     DeviceScope scope(cfg->device);
@@ -168,6 +176,10 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out)
     if (e == hipSuccess && !cfg->ipm_cold_start) {
         e = hipMalloc(&h->ipm_ws, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
         if (e == hipSuccess) e = hipMemset(h->ipm_ws, 0, B * mpc::IPM_WARM_DOUBLES * sizeof(double));
+    }
+    if (e == hipSuccess && cfg->emulate_acados) {
+        e = hipMalloc(&h->sqp_x, B * 6 * ((size_t)cfg->N + 1) * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(h->sqp_x, 0, B * 6 * ((size_t)cfg->N + 1) * sizeof(double));
     }
     if (e == hipSuccess) e = hipMalloc(&h->sqp, B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->sqp, 0, B * sizeof(int));
@@ -190,7 +202,7 @@ void mpc_destroy(mpc_handle *h)
     (void)hipFree(h->Hws); (void)hipFree(h->lane_ws); (void)hipFree(h->term_C); (void)hipFree(h->stat); (void)hipFree(h->iters); (void)hipFree(h->status);
     (void)hipFree(h->stats_out); (void)hipFree(h->mp_scen); (void)hipFree(h->cost_scen); (void)hipFree(h->sqp); (void)hipFree(h->ipm_ws);
     (void)hipFree(h->sh_H); (void)hipFree(h->sh_Kref); (void)hipFree(h->sh_Kx); (void)hipFree(h->sh_T); (void)hipFree(h->as2);
-    (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue);
+    (void)hipFree(h->work); (void)hipFree(h->order); (void)hipFree(h->queue); (void)hipFree(h->sqp_x);
     if (h->host_stage) (void)hipHostFree(h->host_stage);
     delete h;
 }
@@ -234,9 +246,19 @@ int mpc_set_terminal_set(mpc_handle *h, int m, const double *C_host)
     if (!h) return MPC_EINVAL;
     ON_HANDLE_DEVICE(h);
     if (m < 0 || m > MPC_MAX_TERMINAL_ROWS || (m > 0 && !C_host)) return fail(h, MPC_EINVAL, "mpc_set_terminal_set: 0 <= m <= MPC_MAX_TERMINAL_ROWS rows of 5 doubles");
-    if (m > 0 && !h->lanes)
-        return fail(h, MPC_EINVAL, "mpc_set_terminal_set: general terminal rows are solved stage-wise; create the controller with solver_layout = MPC_LAYOUT_LANE");
     if (m > 0 && h->cfg.kind == MPC_KIND_NL) return fail(h, MPC_EINVAL, "mpc_set_terminal_set: linear controllers only");
+    if (m > 0 && !h->lanes) {
+        // General terminal rows are solved stage-wise.  A handle whose layout was left to the library moves to the
+        // lane-per-scenario kernel here (it stays there when the set is removed again); one created with
+        // MPC_LAYOUT_WAVE keeps what its caller asked for and refuses the rows.
+        if (h->cfg.solver_layout != MPC_LAYOUT_AUTO || h->sqp_x)
+            return fail(h, MPC_EINVAL, "mpc_set_terminal_set: general terminal rows are solved stage-wise; create the controller with solver_layout = MPC_LAYOUT_AUTO or MPC_LAYOUT_LANE");
+        HIP_TRY(h, hipDeviceSynchronize());
+        double *ws = nullptr;
+        HIP_TRY(h, hipMalloc(&ws, mpc::lanes_workspace_doubles(h->cfg.N, h->cfg.B, 0) * sizeof(double)));
+        h->lane_ws = ws; h->lanes = true; h->sh_on = false; h->order_B = 0;
+        if (h->ipm_ws) HIP_TRY(h, hipMemset(h->ipm_ws, 0, (size_t)h->cfg.B * mpc::IPM_WARM_DOUBLES * sizeof(double)));
+    }
     if (!h->lanes) return MPC_OK;                          // m == 0 on a wave-layout handle: nothing to remove
     HIP_TRY(h, hipDeviceSynchronize());                    // the workspace changes shape: no launch of this handle may be in flight
     // rows, then a workspace with room for their slacks and multipliers; on failure the handle keeps what it had
@@ -305,7 +327,9 @@ int mpc_condense_fixed(mpc_handle *h, void *stream, double vx, int exclusive)
 
 static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
 {
-    if (h->sh_on && !h->mp_scen && !h->cost_scen) {
+    a.sqp_x = h->sqp_x;                  // emulate_acados (NULL otherwise): the regularised problem is condensed per scenario
+    if (h->sqp_x) a.sqp_out = h->sqp;
+    if (h->sh_on && !h->mp_scen && !h->cost_scen && !h->sqp_x) {
         a.sh_H = h->sh_H; a.sh_Kref = h->sh_Kref; a.sh_Kx = h->sh_Kx; a.sh_vx = h->sh_vx; a.sh_mask = h->sh_mask; a.sh_exclusive = h->sh_exclusive ? 1 : 0;
         a.sh_T = h->sh_T_ok ? h->sh_T : nullptr;
     }
@@ -549,6 +573,7 @@ int mpc_reset_warm_start(mpc_handle *h, void *stream)
     if (h->ipm_ws) HIP_TRY(h, hipMemsetAsync(h->ipm_ws, 0, (size_t)h->cfg.B * mpc::IPM_WARM_DOUBLES * sizeof(double), (hipStream_t)stream));
     h->order_B = 0;
     if (h->queue) HIP_TRY(h, hipMemsetAsync(h->queue, 0, 2 * sizeof(int), (hipStream_t)stream));
+    if (h->sqp_x) HIP_TRY(h, hipMemsetAsync(h->sqp_x, 0, (size_t)h->cfg.B * 6 * ((size_t)h->cfg.N + 1) * sizeof(double), (hipStream_t)stream));
     return MPC_OK;
 }
 
@@ -570,6 +595,7 @@ int mpc_solve_only_noalloc(const mpc_config *cfg, void *stream, int B, const dou
 {
     if (!cfg) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: null configuration");
     if (const char *why = check_config(cfg, false)) return fail(nullptr, MPC_EINVAL, std::string("mpc_solve_only_noalloc: ") + why);   // cfg->B sizes a handle's workspace: not read here
+    if (cfg->emulate_acados) return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: emulate_acados keeps an iterate between calls: use a handle");
     if (cfg->kind != MPC_KIND_L && cfg->kind != MPC_KIND_OFL)
         return fail(nullptr, MPC_EINVAL, "mpc_solve_only_noalloc: kinds L and OFL only (LPV and NL carry state between calls: use a handle)");
     if (!mpc::horizon_templated(cfg->N) || cfg->N > NOALLOC_MAX_N)
@@ -609,7 +635,7 @@ int mpc_get_stats(mpc_handle *h, void *stream, double *host_out)
     if (!h || !host_out) return MPC_EINVAL;
     if (h->last_B < 1) return fail(h, MPC_EINVAL, "mpc_get_stats: no solve has been issued");
     ON_HANDLE_DEVICE(h);
-    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, h->cfg.kind == MPC_KIND_NL ? h->sqp : nullptr, h->as2,
+    HIP_TRY(h, mpc::launch_stats((hipStream_t)stream, h->last_B, h->stat, h->iters, h->status, (h->cfg.kind == MPC_KIND_NL || h->sqp_x) ? h->sqp : nullptr, h->as2,
                                  h->cl_valid, h->dev, h->cost_scen, h->stats_out + MPC_STATS_LEN, h->stats_out));
     HIP_TRY(h, hipMemcpyAsync(host_out, h->stats_out, MPC_STATS_LEN * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));

@@ -27,6 +27,8 @@ struct DevCfg {
     // nonlinear controller (MPC_KIND_NL) only
     double w_nl[8], we_nl[7], eps_nl, sqp_tol;
     int sqp_max_iter;
+    // mpc_config.emulate_acados: regularisation and stop tolerance of the emulated SQP iteration
+    double reg_eps, kkt_tol;
 };
 
 struct SolveArgs {
@@ -80,6 +82,9 @@ struct SolveArgs {
     int term_m;
     const double *term_C;
     int px_free;             // no cost on the longitudinal position anywhere (lane layout: the solver build without px)
+    // mpc_config.emulate_acados: the SQP iterate (predicted states of the previous solve) per scenario, [B][6][N+1], read as
+    // the anchor of the regularisation and updated; NULL = off
+    double *sqp_x;
 };
 
 // Raises a kernel's dynamic-LDS limit to the CU's 160 KB once per device and kernel (`done` is that kernel's flag table).

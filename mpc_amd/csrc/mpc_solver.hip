@@ -42,7 +42,8 @@ namespace mpc {
 // with W_k = dt*diag(w) for k < N and the dense terminal weight at k = N.  The weighted columns W_k v_i are
 // exchanged through LDS (s_wv).  gref_out (optional) receives (W_k v)[c], c = 0..2: minus d g / d ref_c(k).
 // s_ref is laid out [c][k] with row length N + 1.
-template <int N, int NF>
+// NR = 6: s_ref holds a reference row for every state ([6][N+1], terminal row included as it is to be used).
+template <int N, int NF, int NR = 3>
 __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const double *s_stage, const double *s_ref,
                                          double *s_wv, const double *s_We, const double (&wq)[6], double f35, double f45,
                                          const double (&c01s)[NF], const double (&c3)[NF], double (&xf)[NF][6],
@@ -94,7 +95,12 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
         for (int f = 0; f < NF; f++) {
             double err[6] = {xf[f][0], xf[f][1], xf[f][2], xf[f][3], xf[f][4], xf[f][5]};
             // the LPV terminal reference stays at the constructor's zeros (LPVMPC.py:220-221)
-            if (s_ref && f == 0 && !(k == N && cfg.kind == MPC_KIND_LPV)) {
+            if (NR == 6) {
+                if (s_ref && f == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) err[c] -= s_ref[c * (N + 1) + k];
+                }
+            } else if (s_ref && f == 0 && !(k == N && cfg.kind == MPC_KIND_LPV)) {
                 err[0] -= s_ref[k]; err[1] -= s_ref[(N + 1) + k]; err[2] -= s_ref[2 * (N + 1) + k];
             }
 #pragma unroll
@@ -191,11 +197,14 @@ constexpr int FIXED_WPB = 4;
 
 // PULL: the work-queue form of the fixed-model kernel (fused launches); its own instantiation, so that the one-step
 // launches keep the straight-line body
-template <int N, bool GENERAL, bool PULL = false>
+// EMUL: the per-scenario condensing kernel with the SQP iteration of mpc_config.emulate_acados around its solve (what
+// acados' MIRROR regularisation and stop rule do to the linear-quadratic problem, LMPC2.py:262-288); its own instantiation.
+template <int N, bool GENERAL, bool PULL = false, bool EMUL = false>
 __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(const DevCfg cfg,
                                                                                           const SolveArgs a)
 {
     static_assert(!(GENERAL && PULL), "the work queue belongs to the fixed-model kernel");
+    static_assert(GENERAL || !EMUL, "the regularised problem is condensed per scenario");
     constexpr int WPB = GENERAL ? 1 : FIXED_WPB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps scenario addressing scalar
     const int lane = threadIdx.x & 63;
@@ -216,8 +225,23 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
+    double *s_ref6 = EMUL ? s_We + 36 : nullptr;          // EMUL: the references the regularised problem is condensed with, [6][N+1]
+    unsigned reg_term = 0;                                 // EMUL: states the terminal weight leaves alone (bit c)
     if (GENERAL) {
         if (lane < 36) s_We[lane] = (a.cost_scen && widx < a.B) ? a.cost_scen[43 * (size_t)s + 7 + lane] : cfg.We[lane];
+        if (EMUL) {
+            // acados mirrors the eigenvalues of every Hessian block below reg_epsilon up to it: in the terminal block
+            // that touches the states whose row and column are zero
+            wave_sync();
+            bool zero = lane < 6;
+            if (lane < 6) {
+                for (int j = 0; j < 6; j++) zero = zero && s_We[lane * 6 + j] == 0.0 && s_We[j * 6 + lane] == 0.0;
+            }
+            reg_term = (unsigned)__ballot(zero);
+            wave_sync();
+            if (zero) s_We[lane * 7] = cfg.reg_eps;
+            wave_sync();
+        }
     } else {
         int ci = 0;
 #pragma unroll
@@ -304,6 +328,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
     int iters_tot = 0, status_max = 0, nconstr = 0, lap_flag = 0, work_tot = 0;
+    int sqp_tot = 0;                    // EMUL: SQP steps of the scenario's solves
     if (lane == 0 && a.as_out && !a.accumulate) { int *o = a.as_out + 6 * (size_t)s; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; }
     double mu = 0.0, res = 0.0, u0 = 0.0;
 
@@ -382,90 +407,195 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         bool need_ipm = false, solved_warm = false;
         const double *Hm;
 
-        bool fast = !GENERAL || a.sh_H != nullptr;
-        if (fast) {
-            bool same = true;
-            for (int k = lane; k <= N; k += WAVE) same = same && (s_p[k] == a.sh_vx);
-            fast = __all(same);
-        }
-        wave_sync();
-        if (fast) {
-            // Every stage runs at the cached speed: U_unc = -inv(H) g is affine in (vy, r, delta, d_hat, references)
-            // with coefficient matrices condensed once by k_condense_fixed.
-            Hm = a.sh_H;
-            const double *Kx = GENERAL ? a.sh_Kx : s_Kx;
-            double acc = 0.0;
-            if (valid)
-                acc = Kx[lane] * xh3 + Kx[N + lane] * xh4 + Kx[2 * N + lane] * xh5 + Kx[3 * N + lane] + Kx[4 * N + lane] * dhat;
-            int ci = 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (a.sh_mask & (1 << c)) {
-                    const double *Kc = GENERAL ? a.sh_Kref + (size_t)c * N * N : s_K + ci * N * N;
-                    const double *rc = s_ref + c * (N + 1) + 1;      // reference of stage kk + 1, read as an LDS broadcast
-                    acc += dot_column<N>(Kc, rc, valid ? lane : 0);        // lanes beyond N repeat column 0 and are zeroed below
-                    ci++;
-                }
-            }
-            const double Uu = valid ? acc : 0.0;
-            const double vd = dt * incl_prefix(Uu, lane);
-            bool ok = fabs(Uu) <= umax;
-            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
-            // (the expectation is for the register allocator: what it has to move out of the way of the call below belongs
-            // on that branch, not on the path every step takes)
-            if (__builtin_expect(__all(ok), 1)) U = Uu;
-            else {
-                constrained = 1;
-                // (s_ref is dead once U_unc is formed: the solvers borrow it)
-                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
-                const ConstrainedResult r = solve_constrained<N, GENERAL ? 1 : 2>(prm, lane, Hm, a.sh_T, Uu, vd, up_d, lo_d, s_ref,
-                                                                                  a.as_out ? a.as_out + 6 * (size_t)s : nullptr,
-                                                                                  a.mode == MODE_OFL ? ASET_CAP_LARGE_NOISY : ASET_CAP_LARGE);
-                U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
-                solved_warm = (warm_rec != nullptr) && r.warm_valid;
-                work_tot += r.work;
-            }
-        } else if (!GENERAL) {
-            Hm = a.sh_H;
-            status = 3;
-        } else {
+        if constexpr (EMUL) {
+            // What acados' solver options do to this linear-quadratic problem (LMPC2.py:262-288), per SQP step: the stage
+            // weights below reg_epsilon become reg_epsilon (MIRROR) with the previous iterate as their reference, the
+            // full step is taken, and steps repeat until the stationarity residual that leaves behind,
+            // reg_epsilon * max |x - x_prev| over the regularised states, is below the KKT tolerance.
             double *Hw = a.Hws + (size_t)s * N * N;
             Hm = Hw;
-            Newton<N> nt;
             double wq[6];
+            unsigned reg_stage = 0;
 #pragma unroll
-            for (int c = 0; c < 6; c++) wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);   // acados scales stage costs by the time step
-            double xf[1][6] = {{0, 0, 0, xh3, xh4, xh5}};
-            const double c01s[1] = {1.0}, c3s[1] = {c3};
-            double gs[1] = {0.0};
-            condense<N, 1>(cfg, lane, s_stage, s_ref, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
-            g = gs[0];
-            const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
-            const double wrd = opaque_value(wr);      // keeps the N one-hot addends (and their N compare masks)
-            const int lane_d = opaque_int(lane);      // out of hoisted, spilled registers
-#pragma unroll
-            for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
-            if (valid) {                            // one divergent region for all N stores, not one per entry
-                store_column<N>(Hw + lane, nt.row);
+            for (int c = 0; c < 6; c++) {
+                wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);
+                if (fabs(wq[c]) < cfg.reg_eps) { wq[c] = cfg.reg_eps; reg_stage |= 1u << c; }
             }
-            if (!valid) g = 0.0;
-            nt.template factor<false>(lane, (ldouble *)s_wv);
-            const double Uu = valid ? nt.solve(-g, lane) : 0.0;
-            const double vd = dt * incl_prefix(Uu, lane);
-            bool ok = fabs(Uu) <= umax;
-            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
-            if (__all(ok)) U = Uu;
-            else { constrained = 1; need_ipm = true; }
+            const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
+            double *anc = a.sqp_x + (size_t)s * 6 * (N + 1);      // the iterate: lane k reads and writes stage k, lane 0 stage N too
+            int sq = 0;
+#pragma unroll 1
+            for (;;) {
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const double base = c < 3 ? s_ref[c * (N + 1) + lane] : 0.0;
+                        s_ref6[c * (N + 1) + lane] = ((reg_stage >> c) & 1) ? anc[c * (N + 1) + lane] : base;
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        // (the LPV controller never sets its terminal reference: LPVMPC.py:220-221)
+                        const double base = (c < 3 && cfg.kind != MPC_KIND_LPV) ? s_ref[c * (N + 1) + N] : 0.0;
+                        s_ref6[c * (N + 1) + N] = ((reg_term >> c) & 1) ? anc[c * (N + 1) + N] : base;
+                    }
+                }
+                wave_sync();
+                Newton<N> nt;
+                double xf[1][6] = {{0, 0, 0, xh3, xh4, xh5}};
+                const double c01s[1] = {1.0}, c3s[1] = {c3};
+                double gs[1] = {0.0};
+                condense<N, 1, 6>(cfg, lane, s_stage, s_ref6, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
+                g = gs[0];
+                const double wrd = opaque_value(wr);
+                const int lane_d = opaque_int(lane);
+#pragma unroll
+                for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
+                if (valid) {
+                    store_column<N>(Hw + lane, nt.row);
+                }
+                if (!valid) g = 0.0;
+                nt.template factor<false>(lane, (ldouble *)s_wv);
+                const double Uu = valid ? nt.solve(-g, lane) : 0.0;
+                const double vd = dt * incl_prefix(Uu, lane);
+                bool ok = fabs(Uu) <= umax;
+                if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+                if (__all(ok)) { U = Uu; warm_ok = false; }
+                else {
+                    constrained = 1;
+                    // the first step of a call starts from the previous closed-loop step's solve moved one stage ahead,
+                    // the following ones from the step before them
+                    const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? (sq == 0 ? 2 : 1) : 0, N};
+                    const IpmResult r = interior_point<N, 1>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)s_wv);
+                    U = r.U; mu = r.mu; res = r.res; iters += r.iters; status = max(status, r.status);
+                    work_tot += 4 * r.iters;
+                    warm_ok = (warm_rec != nullptr) && r.warm_valid;
+                }
+                // the step's states, against the iterate
+                double x[6] = {0, 0, 0, xh3, xh4, xh5};
+                double keep[6] = {0, 0, 0, xh3, xh4, xh5};
+#pragma unroll 1
+                for (int k = 0; k < N; k++) {
+                    const double *st = &s_stage[k * STAGE_W];
+                    const double uk = bcast(U, k);
+                    const double n0 = x[0] + st[0] * x[2] + st[1] * x[3] + st[8];
+                    const double n1 = x[1] + st[2] * x[2] + st[3] * x[3] + st[9];
+                    const double n2 = x[2] + dt * x[4];
+                    const double n3 = st[4] * x[3] + st[5] * x[4] + f35 * x[5] + c3;
+                    const double n4 = st[6] * x[3] + st[7] * x[4] + f45 * x[5];
+                    const double n5 = x[5] + dt * uk;
+                    x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3; x[4] = n4; x[5] = n5;
+                    if (lane == k + 1) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) keep[c] = x[c];
+                    }
+                }
+                double dmaxv = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    if (valid) {
+                        if ((reg_stage >> c) & 1) dmaxv = fmax(dmaxv, fabs(keep[c] - anc[c * (N + 1) + lane]));
+                        anc[c * (N + 1) + lane] = keep[c];
+                    }
+                    if (lane == 0) {
+                        if ((reg_term >> c) & 1) dmaxv = fmax(dmaxv, fabs(x[c] - anc[c * (N + 1) + N]));
+                        anc[c * (N + 1) + N] = x[c];
+                    }
+                }
+                const double kkt = cfg.reg_eps * wave_max(dmaxv);
+                sq++;
+                if (kkt <= cfg.kkt_tol) break;
+                if (sq >= cfg.sqp_max_iter) { status = max(status, 1); break; }
+                wave_sync();
+            }
+            sqp_tot += sq;
+        } else {
+            bool fast = !GENERAL || a.sh_H != nullptr;
+            if (fast) {
+                bool same = true;
+                for (int k = lane; k <= N; k += WAVE) same = same && (s_p[k] == a.sh_vx);
+                fast = __all(same);
+            }
+            wave_sync();
+            if (fast) {
+                // Every stage runs at the cached speed: U_unc = -inv(H) g is affine in (vy, r, delta, d_hat, references)
+                // with coefficient matrices condensed once by k_condense_fixed.
+                Hm = a.sh_H;
+                const double *Kx = GENERAL ? a.sh_Kx : s_Kx;
+                double acc = 0.0;
+                if (valid)
+                    acc = Kx[lane] * xh3 + Kx[N + lane] * xh4 + Kx[2 * N + lane] * xh5 + Kx[3 * N + lane] + Kx[4 * N + lane] * dhat;
+                int ci = 0;
+    #pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (a.sh_mask & (1 << c)) {
+                        const double *Kc = GENERAL ? a.sh_Kref + (size_t)c * N * N : s_K + ci * N * N;
+                        const double *rc = s_ref + c * (N + 1) + 1;      // reference of stage kk + 1, read as an LDS broadcast
+                        acc += dot_column<N>(Kc, rc, valid ? lane : 0);        // lanes beyond N repeat column 0 and are zeroed below
+                        ci++;
+                    }
+                }
+                const double Uu = valid ? acc : 0.0;
+                const double vd = dt * incl_prefix(Uu, lane);
+                bool ok = fabs(Uu) <= umax;
+                if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+                // (the expectation is for the register allocator: what it has to move out of the way of the call below belongs
+                // on that branch, not on the path every step takes)
+                if (__builtin_expect(__all(ok), 1)) U = Uu;
+                else {
+                    constrained = 1;
+                    // (s_ref is dead once U_unc is formed: the solvers borrow it)
+                    const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
+                    const ConstrainedResult r = solve_constrained<N, GENERAL ? 1 : 2>(prm, lane, Hm, a.sh_T, Uu, vd, up_d, lo_d, s_ref,
+                                                                                      a.as_out ? a.as_out + 6 * (size_t)s : nullptr,
+                                                                                      a.mode == MODE_OFL ? ASET_CAP_LARGE_NOISY : ASET_CAP_LARGE);
+                    U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
+                    solved_warm = (warm_rec != nullptr) && r.warm_valid;
+                    work_tot += r.work;
+                }
+            } else if (!GENERAL) {
+                Hm = a.sh_H;
+                status = 3;
+            } else {
+                double *Hw = a.Hws + (size_t)s * N * N;
+                Hm = Hw;
+                Newton<N> nt;
+                double wq[6];
+    #pragma unroll
+                for (int c = 0; c < 6; c++) wq[c] = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + c] : cfg.w[c]);   // acados scales stage costs by the time step
+                double xf[1][6] = {{0, 0, 0, xh3, xh4, xh5}};
+                const double c01s[1] = {1.0}, c3s[1] = {c3};
+                double gs[1] = {0.0};
+                condense<N, 1>(cfg, lane, s_stage, s_ref, s_wv, s_We, wq, f35, f45, c01s, c3s, xf, nt.row, gs, nullptr);
+                g = gs[0];
+                const double wr = dt * (a.cost_scen ? a.cost_scen[43 * (size_t)s + 6] : cfg.w[6]);
+                const double wrd = opaque_value(wr);      // keeps the N one-hot addends (and their N compare masks)
+                const int lane_d = opaque_int(lane);      // out of hoisted, spilled registers
+    #pragma unroll
+                for (int i = 0; i < N; i++) nt.row[i] += (i == lane_d) ? wrd : 0.0;
+                if (valid) {                            // one divergent region for all N stores, not one per entry
+                    store_column<N>(Hw + lane, nt.row);
+                }
+                if (!valid) g = 0.0;
+                nt.template factor<false>(lane, (ldouble *)s_wv);
+                const double Uu = valid ? nt.solve(-g, lane) : 0.0;
+                const double vd = dt * incl_prefix(Uu, lane);
+                bool ok = fabs(Uu) <= umax;
+                if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+                if (__all(ok)) U = Uu;
+                else { constrained = 1; need_ipm = true; }
+            }
+            if (need_ipm) {
+                // closed loops start the interior point from the previous step's solve when that step needed one too
+                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
+                const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)(GENERAL ? s_wv : s_ref));   // both areas are dead by now
+                U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
+                work_tot += 4 * r.iters;
+                warm_ok = (warm_rec != nullptr) && r.warm_valid;
+            } else
+                warm_ok = solved_warm;                 // the fixed-model solve left its result in the record, or no solve was needed
         }
-        if (need_ipm) {
-            // closed loops start the interior point from the previous step's solve when that step needed one too
-            const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
-            const IpmResult r = interior_point<N, GENERAL ? 1 : 2>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)(GENERAL ? s_wv : s_ref));   // both areas are dead by now
-            U = r.U; mu = r.mu; res = r.res; iters = r.iters; status = r.status;
-            work_tot += 4 * r.iters;
-            warm_ok = (warm_rec != nullptr) && r.warm_valid;
-        } else
-            warm_ok = solved_warm;                 // the fixed-model solve left its result in the record, or no solve was needed
         if (relaxed) status = max(status, 4);    // solved with the steering bound widened: the posed QP was infeasible
         status = max(status, lap_flag);
 
@@ -583,6 +713,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
         a.status_own[s] = st_all; a.iters_own[s] = it_all;
         if (a.status_out) a.status_out[s] = st_all;
         if (a.iters_out) a.iters_out[s] = it_all;
+        if (EMUL && a.sqp_out) a.sqp_out[s] = a.accumulate ? a.sqp_out[s] + sqp_tot : sqp_tot;
         if (a.stat_out) {
             double *so = a.stat_out + STAT_W * (size_t)s;
             so[0] = mu; so[1] = res; so[2] = (a.accumulate ? so[2] : 0.0) + (double)nconstr; so[3] = fabs(u0);
@@ -727,8 +858,9 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         else hipLaunchKernelGGL((k_mpc<N, false, false>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
         const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
-        const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36);
-        hipLaunchKernelGGL((k_mpc<N, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+        const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36 + (a.sqp_x ? 6 * (N + 1) : 0));
+        if (a.sqp_x) hipLaunchKernelGGL((k_mpc<N, true, false, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
+        else hipLaunchKernelGGL((k_mpc<N, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
     }
     return hipGetLastError();
 }

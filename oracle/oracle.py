@@ -453,8 +453,10 @@ class AcadosEmulation:
     stationarity residual the regularisation leaves behind, reg_eps * max|x - x_prev| over the regularised components,
     is below `tol` (the other KKT residuals of a full step on a linear-quadratic problem are at the QP solver's 1e-8)."""
 
-    def __init__(self, orc: Oracle, cfg, reg_eps: float = 1e-4, tol: float = 1e-4, max_iter: int = 200):
-        self.orc, self.cfg, self.reg_eps, self.tol, self.max_iter = orc, cfg, reg_eps, tol, max_iter
+    def __init__(self, orc: Oracle, cfg, reg_eps: float = 1e-4, tol: float = 1e-4, max_iter: int = 200, qp_tol=(1e-8, 1e-8, 50)):
+        """qp_tol: accuracy of the QP solves (complementarity, residual, iteration cap); the default stands for HPIPM's,
+        orc.tol drives every QP to the accuracy of the arithmetic (what the library's emulate_acados mode is compared with)."""
+        self.orc, self.cfg, self.reg_eps, self.tol, self.max_iter, self.qp_tol = orc, cfg, reg_eps, tol, max_iter, qp_tol
         N = int(cfg[1])
         self.x_prev = np.zeros((N + 1, 6))          # acados starts from a zero iterate
         self.sqp_iterations = []
@@ -471,7 +473,7 @@ class AcadosEmulation:
         for it in range(1, self.max_iter + 1):
             st, traj, U, x, info = self.orc.optimize_sqp_step(self.cfg, x0_7, wp, p, self.x_prev, self.reg_eps, d_hat,
                                                              None if lin_x is None else lin_x.copy(),
-                                                             None if lin_u is None else lin_u.copy())
+                                                             None if lin_u is None else lin_u.copy(), tol=self.qp_tol)
             d = np.abs(x - self.x_prev)
             res = self.reg_eps * max(d[:-1][:, w_stage].max(initial=0.0), d[-1][w_term].max(initial=0.0))
             self.x_prev = x

@@ -1,0 +1,93 @@
+"""mpc_config.emulate_acados on the GPU against the checker's emulation of the reference's solver set-up
+(oracle.AcadosEmulation / orc_mpc_optimize_sqp_step: MIRROR regularisation about the iterate kept between calls, full SQP
+steps until the KKT tolerance; LMPC2.py:262-288).  As unpinned as the emulation it follows: acados itself cannot run here."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(u_ref, umax=0.9):
+    return 1e-5 * np.maximum(np.abs(u_ref), 1e-3 * umax)
+
+
+def _checker_loop(orc, kind, N, Tf, st0, nsteps):
+    from oracle import oracle as O
+    cfg = O.make_cfg(kind, N, Tf)
+    emu = O.AcadosEmulation(orc, cfg, qp_tol=orc.tol)
+    st = st0.copy(); lap = 0; pp = 0.0
+    lx = np.zeros((6, N + 1)); lu = np.zeros(N)
+    us, Us = [], []
+    for _ in range(nsteps):
+        wp, sp, _, pp = orc.skidpad_waypoints(st[0], st[1], np.arctan2(st[3], st[2]), lap, pp, st[4], N, Tf / N)
+        red = st[[0, 1, 2, 3, 5, 6, 7]]
+        if kind == "LPV":
+            _, traj, U = emu.optimize(red, wp, sp, 0.0, lx, lu)
+            lx = emu.x_prev.T.copy(); lu = U.copy()               # LPVMPC.py:313-327: prev_x, prev_u <- the solution
+        else:
+            _, traj, U = emu.optimize(red, wp, sp)
+        oldx = st[0]
+        st = orc.plant_rk4(st, U[0], Tf / N, cfg[3:9])
+        if st[0] > 16.75 and oldx <= 16.75:
+            lap += 1
+        us.append(U[0]); Us.append(U)
+    return np.array(us), np.array(Us), st, emu.sqp_iterations
+
+
+@pytest.mark.parametrize("kind,N,Tf", [("L", 50, 0.5), ("L", 10, 0.5), ("LPV", 50, 0.5)])
+def test_emulated_closed_loop_matches_checker_emulation(orc80, kind, N, Tf):
+    import torch
+    from mpc_amd.batched import SkidpadBatch
+    nsteps = 40
+    starts = np.array([[15.0, 0.1, 1.0, 0.0, 8.0, 0.0, 0.0, 0.0],
+                       [15.0, -0.25, np.cos(0.08), np.sin(0.08), 8.0, 0.15, -0.1, 0.03]])
+    sim = SkidpadBatch(N, Tf, starts, model=kind, emulate_acados=True)
+    xs, us = sim.run(nsteps, record=True)
+    torch.cuda.synchronize()
+    us = us.cpu().numpy()
+    stats = sim.ocp.stats()
+    total_sqp = 0
+    for b in range(2):
+        u_ref, _, st_ref, sqp = _checker_loop(orc80, kind, N, Tf, starts[b], nsteps)
+        err = np.abs(us[:, b] - u_ref)
+        assert (err <= 10 * _tol(u_ref)).all(), (kind, b, int(np.argmax(err / _tol(u_ref))), err.max())
+        np.testing.assert_allclose(sim.state.cpu().numpy()[b], st_ref, rtol=0, atol=1e-7)
+        total_sqp += sum(sqp)
+    assert stats["sum_sqp_iterations"] == total_sqp              # the same number of SQP steps, call by call
+    assert (sim.status.cpu().numpy() == 0).all()
+    # and it is not the minimiser: the same loops without the emulation differ by what DESIGN quantifies (~1e-3 rad/s)
+    plain = SkidpadBatch(N, Tf, starts, model=kind)
+    _, up = plain.run(nsteps, record=True)
+    diff = np.abs(up.cpu().numpy() - us).max()
+    assert 1e-6 < diff < 5e-2, diff
+
+
+def test_emulated_optimize_carries_the_iterate_and_resets(orc80):
+    """Single-controller surface: the iterate lives in the handle from call to call (two SQP steps on the first call from
+    the zero iterate, then one), and reset_warm_start() returns to a new solver object's zero iterate."""
+    from oracle import oracle as O
+    from mpc_amd.controllers import LOcp
+    N, Tf = 50, 0.5
+    cfg = O.make_cfg("L", N, Tf)
+    ctl = LOcp(N, Tf, emulate_acados=True)
+    st = np.array([15.0, 0.1, 1.0, 0.0, 8.0, 0.0, 0.0, 0.0])
+    wp, sp, _, _ = orc80.skidpad_waypoints(st[0], st[1], 0.0, 0, 0.0, 8.0, N, Tf / N)
+    red = st[[0, 1, 2, 3, 5, 6, 7]]
+    emu = O.AcadosEmulation(orc80, cfg, qp_tol=orc80.tol)
+    for call in range(3):
+        _, traj_ref, U_ref = emu.optimize(red, wp, sp)
+        status, traj, inputs = ctl.optimize(red, wp, sp)
+        assert (np.abs(inputs[:, 0] - U_ref) <= _tol(U_ref)).all(), call
+        assert ctl.stats()["sum_sqp_iterations"] == emu.sqp_iterations[-1]
+    first = emu.sqp_iterations[0]
+    ctl.reset_warm_start()
+    ctl.optimize(red, wp, sp)
+    assert ctl.stats()["sum_sqp_iterations"] == first
+
+
+def test_emulation_argument_checks():
+    from mpc_amd.controllers import LOcp, NLOcp
+    with pytest.raises(RuntimeError, match="emulate_acados"):
+        LOcp(80, 0.8, emulate_acados=True)                      # no register-resident kernel at that horizon
+    with pytest.raises(RuntimeError, match="emulate_acados"):
+        LOcp(50, 0.5, emulate_acados=True, solver_layout="lane")

@@ -170,6 +170,9 @@ def test_terminal_set_argument_checks():
     C = np.zeros((3, 5)); C[:, 4] = 1.0
     with pytest.raises(RuntimeError, match="MPC_LAYOUT_LANE"):
         LOcp(50, 0.5, batch=4, solver_layout="wave", terminal_set=C)
+    w = LOcp(50, 0.5, batch=4, solver_layout="wave")
+    with pytest.raises(RuntimeError, match="MPC_LAYOUT_LANE"):
+        w.set_terminal_set(C)
     ctl = LOcp(50, 0.5, batch=4, solver_layout="lane")
     with pytest.raises(RuntimeError, match="MPC_MAX_TERMINAL_ROWS"):
         ctl.set_terminal_set(np.zeros((257, 5)))
@@ -194,3 +197,34 @@ def test_unreachable_terminal_set_is_reported(orc80):
     finally:
         orc80.set_terminal_set(None)
     assert ref == [2] * B and (status.cpu().numpy() == 2).all()
+
+
+def test_auto_layout_handle_moves_to_the_stage_wise_solver(orc64):
+    """A controller whose layout was left to the library (it starts on the wavefront-per-scenario kernels) takes a
+    terminal set later on: mpc_set_terminal_set moves the handle to the lane-per-scenario solver, and its answers are
+    those of a controller created there."""
+    import torch
+    from mpc_amd.controllers import LOcp
+    N, Tf, B = 50, 0.5, 8
+    rng = np.random.default_rng(4)
+    psi = rng.uniform(-0.1, 0.1, B)
+    st = np.stack([np.full(B, 15.0), rng.uniform(-0.3, 0.3, B), np.cos(psi), np.sin(psi), np.full(B, 8.0),
+                   rng.uniform(-0.2, 0.2, B), rng.uniform(-0.2, 0.2, B), rng.uniform(-0.05, 0.05, B)], axis=1)
+    wps, ps = [], []
+    for s_ in st:
+        wp, sp, _, _ = orc64.skidpad_waypoints(s_[0], s_[1], np.arctan2(s_[3], s_[2]), 0, 0.0, s_[4], N, Tf / N)
+        wps.append(wp); ps.append(sp)
+    x0 = st[:, [0, 1, 2, 3, 5, 6, 7]]; wps = np.array(wps); ps = np.array(ps)
+    a = LOcp(N, Tf, batch=B)                                   # auto: wave layout
+    U0, traj0, _, _ = a.solve_batched(x0, wps, ps)
+    torch.cuda.synchronize()
+    err = np.array([_terminal_error("L", traj0[b].cpu().numpy(), wps[b]) for b in range(B)])
+    d = np.array([0.0, 1.0, 0.3, -0.2, 0.5])
+    C = (d / (0.85 * np.abs(err @ d).max()))[None, :] * np.array([[1.0], [-1.0]])
+    a.set_terminal_set(C)
+    b = LOcp(N, Tf, batch=B, solver_layout="lane", terminal_set=C)
+    Ua, ta, sa, _ = a.solve_batched(x0, wps, ps)
+    Ub, tb, sb, _ = b.solve_batched(x0, wps, ps)
+    torch.cuda.synchronize()
+    assert torch.equal(Ua, Ub) and torch.equal(ta, tb) and torch.equal(sa, sb)
+    assert not torch.equal(Ua, U0)                             # the rows are active somewhere
