@@ -294,6 +294,16 @@ int mpc_control_buffer_interp(void *stream, int B, int N, double Tf, const doubl
 int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, const double *eig_host, const double *A_host,
                          const double *B_host, const double *K_host, double umax, const double *c, int *ok_out);
 
+/* The linear programmes of estimate_control_amissible_invariant_set (stability.py:26-78; cvxpy / ECOS there), batched:
+ * programme q maximises c[q]' x subject to A x <= b, x free -- nlp objectives c [nlp][d] over one set of m rows A [m][d],
+ * b [m] (all device memory; d <= 6, m <= MPC_LP_MAX_ROWS), one wavefront per programme (primal-dual interior point on the
+ * d x d normal equations).  opt_out [nlp] receives the optima, x_out [nlp][d] (optional) the maximisers, status_out [nlp]
+ * 0 = optimum (gap and residuals 1e-10 relative, plus the rounding floor of rows as large as the data's), 1 = unbounded,
+ * 2 = iteration cap.  x = 0 need not be feasible. */
+#define MPC_LP_MAX_ROWS 4096
+int mpc_lp_maximize(void *stream, int nlp, int d, int m, const double *A, const double *b, const double *c, double *opt_out,
+                    double *x_out, int *status_out);
+
 /* Terminal set of the linear controllers (L, OFL, LPV):  C (x_N[1:] - x_ref) <= 1  on the last predicted state, over
  * (py, psi, vy, r, delta), x_ref = (y_ref, sin psi_ref, 0, 0, 0) of the last reference point (zero for the LPV controller,
  * like its terminal cost reference).  This is the constraint the reference prepares and leaves commented out

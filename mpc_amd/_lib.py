@@ -68,6 +68,7 @@ _SIGS = {
     "mpc_plan_step": ([_vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "mpc_control_buffer_interp": ([_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_double, _vp], C.c_int),
     "mpc_invariance_check": ([_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _vp, _vp], C.c_int),
+    "mpc_lp_maximize": ([_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 6, C.c_int),
     "mpc_get_stats": ([_vp, _vp, _dp], C.c_int),
     "mpc_reset_warm_start": ([_vp, _vp], C.c_int),
     "mpc_set_terminal_set": ([_vp, C.c_int, _vp], C.c_int),

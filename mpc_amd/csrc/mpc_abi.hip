@@ -736,6 +736,15 @@ int mpc_invariance_check(void *stream, int nc, int d, const double *Q_host, cons
     return MPC_OK;
 }
 
+int mpc_lp_maximize(void *stream, int nlp, int d, int m, const double *A, const double *b, const double *c, double *opt_out,
+                    double *x_out, int *status_out)
+{
+    if (nlp < 1 || d < 1 || d > 6 || m < 1 || m > MPC_LP_MAX_ROWS || !A || !b || !c || !opt_out || !status_out)
+        return fail(nullptr, MPC_EINVAL, "mpc_lp_maximize: bad argument (1 <= d <= 6, 1 <= m <= MPC_LP_MAX_ROWS)");
+    AUX_TRY(mpc::launch_lp_maximize((hipStream_t)stream, nlp, d, m, A, b, c, opt_out, x_out, status_out));
+    return MPC_OK;
+}
+
 int mpc_plan_skidpad(void *stream, int B, int N, double dt, const double *pose, const int *lap, double *prev_progress,
                      const double *target_vel, double *wp_out, double *progress_out)
 {

@@ -502,6 +502,194 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------- linear programmes
+// maximise c'x subject to A x <= b (x free, d <= 6 unknowns, m rows), one wavefront per programme, all programmes over the
+// same rows: the loop of estimate_control_amissible_invariant_set (stability.py:26-78) asks 2 (nx + nu) such questions
+// about the set it has built so far, per power of the closed-loop matrix (cvxpy / ECOS there).  Mehrotra
+// predictor-corrector on  A x + s = b,  A'z = c,  s, z >= 0,  s_i z_i = 0:  the Newton step reduces to the d x d system
+// (A' diag(z / s) A) dx = rhs, accumulated row by row (lane l owns rows l, l + 64, ...) and reduced over the wave; every
+// lane then factors and solves it for itself.  Slacks, multipliers and their affine directions live in LDS (4 m doubles).
+// status: 0 optimum (relative gap and residuals <= 1e-10), 1 unbounded (the iterates run off), 2 iteration cap.
+constexpr int LP_D = 6;
+
+__device__ __forceinline__ void lp_solve_spd(const double (&M)[21], const double (&r)[LP_D], int d, double (&x)[LP_D])
+{
+    // Cholesky of the packed lower triangle (entries beyond d: unit diagonal), then the two substitutions
+    double L[LP_D][LP_D];
+#pragma unroll
+    for (int i = 0; i < LP_D; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) L[i][j] = (i < d && j < d) ? M[i * (i + 1) / 2 + j] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < LP_D; j++) {
+        double dj = L[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k];
+        dj = sqrt(fmax(dj, 1e-300));
+        L[j][j] = dj;
+#pragma unroll
+        for (int i = j + 1; i < LP_D; i++) {
+            double v = L[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            L[i][j] = v / dj;
+        }
+    }
+    double y[LP_D];
+#pragma unroll
+    for (int i = 0; i < LP_D; i++) {
+        double v = i < d ? r[i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+        y[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = LP_D - 1; i >= 0; i--) {
+        double v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < LP_D; k++) v -= L[k][i] * x[k];
+        x[i] = v / L[i][i];
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_lp_maximize(int nlp, int d, int m, const double *A, const double *b, const double *c,
+                                                      double *opt_out, double *x_out, int *status_out)
+{
+    extern __shared__ double lp_lds[];
+    double *S = lp_lds, *Z = lp_lds + m, *DS = lp_lds + 2 * (size_t)m, *DZ = lp_lds + 3 * (size_t)m;
+    const int lane = threadIdx.x, q = blockIdx.x;
+    if (q >= nlp) return;
+    double cv[LP_D], x[LP_D];
+#pragma unroll
+    for (int j = 0; j < LP_D; j++) { cv[j] = j < d ? c[(size_t)q * d + j] : 0.0; x[j] = 0.0; }
+    double bscale = 0.0;
+    for (int i = lane; i < m; i += WAVE) { S[i] = fmax(b[i], 1.0); Z[i] = 1.0; bscale = fmax(bscale, fabs(b[i])); }
+    bscale = fmax(1.0, wave_max(bscale));
+    double cscale = 0.0;
+#pragma unroll
+    for (int j = 0; j < LP_D; j++) cscale = fmax(cscale, fabs(cv[j]));
+    cscale = fmax(cscale, 1e-300);
+    int status = 2;
+#pragma unroll 1
+    for (int it = 0; it < 80; it++) {
+        // pass 1: residuals, normal matrix, right-hand side of the affine step
+        double M[21], rd[LP_D], v[LP_D];
+#pragma unroll
+        for (int e = 0; e < 21; e++) M[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) { rd[j] = 0.0; v[j] = 0.0; }
+        double gap = 0.0, rpmax = 0.0, amax = 0.0, zsum = 0.0;
+        for (int i = lane; i < m; i += WAVE) {
+            double a[LP_D], ax = 0.0;
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) { a[j] = j < d ? A[(size_t)i * d + j] : 0.0; ax += a[j] * x[j]; amax = fmax(amax, fabs(a[j])); }
+            const double s = S[i], z = Z[i], rp = ax + s - b[i], w = z / s;
+            gap += s * z; rpmax = fmax(rpmax, fabs(rp)); zsum += z;
+            const double t = (s * z - z * rp) / s;               // S^-1 (r_c - Z r_p), r_c = s z
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) {
+                rd[j] += a[j] * z; v[j] += a[j] * t;
+#pragma unroll
+                for (int k = 0; k <= j; k++) M[j * (j + 1) / 2 + k] += w * a[j] * a[k];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 21; e++) M[e] = wave_sum(M[e]);
+        double rdmax = 0.0, obj = 0.0, xmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) {
+            rd[j] = wave_sum(rd[j]) - cv[j]; v[j] = wave_sum(v[j]);
+            rdmax = fmax(rdmax, fabs(rd[j])); obj += cv[j] * x[j]; xmax = fmax(xmax, fabs(x[j]));
+        }
+        gap = wave_sum(gap); rpmax = wave_max(rpmax); amax = wave_max(amax); zsum = wave_sum(zsum);
+        const double mu = gap / m;
+        // (the residuals cannot fall below the rounding of the sums they are: rows of size amax against x and z)
+        if (gap <= 1e-10 * (1.0 + fabs(obj)) && rpmax <= 1e-10 * bscale + 1e-13 * amax * xmax &&
+            rdmax <= 1e-10 * cscale + 1e-13 * amax * zsum) { status = 0; break; }
+        if (!(xmax < 1e12 * bscale) || !(fabs(obj) < 1e12 * bscale * cscale)) { status = 1; break; }
+        // a whiff of regularisation keeps the factorisation alive when multipliers vanish on all rows that see a direction
+        double tr = 0.0;
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) tr += M[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) M[j * (j + 1) / 2 + j] += 1e-15 * tr + 1e-300;
+        double rhs[LP_D], dx[LP_D];
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) rhs[j] = -rd[j] + v[j];
+        lp_solve_spd(M, rhs, d, dx);
+        // pass 2: affine directions, step to the boundary, complementarity after it
+        double al = 1.0;
+        for (int i = lane; i < m; i += WAVE) {
+            double adx = 0.0, ax = 0.0;
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) { const double aj = j < d ? A[(size_t)i * d + j] : 0.0; adx += aj * dx[j]; ax += aj * x[j]; }
+            const double s = S[i], z = Z[i], rp = ax + s - b[i];
+            const double ds = -rp - adx, dz = (-s * z - z * ds) / s;
+            DS[i] = ds; DZ[i] = dz;
+            if (ds < 0.0) al = fmin(al, -s / ds);
+            if (dz < 0.0) al = fmin(al, -z / dz);
+        }
+        al = wave_min(al);
+        double gaff = 0.0;
+        for (int i = lane; i < m; i += WAVE) gaff += (S[i] + al * DS[i]) * (Z[i] + al * DZ[i]);
+        gaff = wave_sum(gaff);
+        const double sg = gaff / gap, sigmu = sg * sg * sg * mu;
+        // pass 3: corrector right-hand side
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) v[j] = 0.0;
+        for (int i = lane; i < m; i += WAVE) {
+            double a[LP_D], ax = 0.0;
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) { a[j] = j < d ? A[(size_t)i * d + j] : 0.0; ax += a[j] * x[j]; }
+            const double s = S[i], z = Z[i], rp = ax + s - b[i];
+            const double t = (s * z + DS[i] * DZ[i] - sigmu - z * rp) / s;
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) v[j] += a[j] * t;
+        }
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) rhs[j] = -rd[j] + wave_sum(v[j]);
+        lp_solve_spd(M, rhs, d, dx);
+        // pass 4: directions and the step
+        al = 1.0;
+        for (int i = lane; i < m; i += WAVE) {
+            double adx = 0.0, ax = 0.0;
+#pragma unroll
+            for (int j = 0; j < LP_D; j++) { const double aj = j < d ? A[(size_t)i * d + j] : 0.0; adx += aj * dx[j]; ax += aj * x[j]; }
+            const double s = S[i], z = Z[i], rp = ax + s - b[i];
+            const double ds = -rp - adx, dz = (-(s * z + DS[i] * DZ[i] - sigmu) - z * ds) / s;
+            DS[i] = ds; DZ[i] = dz;
+            if (ds < 0.0) al = fmin(al, -s / ds);
+            if (dz < 0.0) al = fmin(al, -z / dz);
+        }
+        al = fmin(1.0, 0.995 * wave_min(al));
+        for (int i = lane; i < m; i += WAVE) { S[i] += al * DS[i]; Z[i] += al * DZ[i]; }
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) x[j] += al * dx[j];       // (every row is always visited by the same lane: no hand-off through LDS)
+    }
+    if (lane == 0) {
+        double obj = 0.0;
+#pragma unroll
+        for (int j = 0; j < LP_D; j++) obj += cv[j] * x[j];
+        opt_out[q] = obj; status_out[q] = status;
+    }
+    if (x_out && lane < d) {
+        double xv = x[0];
+#pragma unroll
+        for (int j = 1; j < LP_D; j++) xv = lane == j ? x[j] : xv;
+        x_out[(size_t)q * d + lane] = xv;
+    }
+}
+
+hipError_t launch_lp_maximize(hipStream_t st, int nlp, int d, int m, const double *A, const double *b, const double *c,
+                              double *opt_out, double *x_out, int *status_out)
+{
+    const size_t lds = sizeof(double) * 4 * (size_t)m;
+    static bool lds_ok[MPC_MAX_DEVICES] = {};
+    if (hipError_t e = allow_big_lds(reinterpret_cast<const void *>(&k_lp_maximize), lds_ok)) return e;
+    hipLaunchKernelGGL(k_lp_maximize, dim3(nlp), dim3(WAVE), lds, st, nlp, d, m, A, b, c, opt_out, x_out, status_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ statistics
 // Reduction of the per-scenario records into MPC_STATS_LEN doubles (sums and maxima; the slots are listed at
 // mpc_get_stats in mpc_amd.h).  Two launches: up to STATS_BLOCKS workgroups write a partial vector each, one workgroup

@@ -139,6 +139,8 @@ hipError_t launch_invariance(hipStream_t st, int nc, int d, const double *Q, con
                              const double *B, const double *K, double umax, const double *c, int *ok_out);
 // reduction of the per-scenario records into MPC_STATS_LEN doubles; part: STATS_BLOCKS * MPC_STATS_LEN doubles of scratch
 constexpr int STATS_BLOCKS = 256;
+hipError_t launch_lp_maximize(hipStream_t st, int nlp, int d, int m, const double *A, const double *b, const double *c,
+                              double *opt_out, double *x_out, int *status_out);
 hipError_t launch_stats(hipStream_t st, int B, const double *stat, const int *iters, const int *status, const int *sqp,
                         const int *as2, bool with_closed_loop, const DevCfg &cfg, const double *cost_scen, double *part, double *out);
 

@@ -1,7 +1,7 @@
 """Terminal-set helpers with the function names of the reference's stability.py.  The vertex test of
-check_control_amissible_invariance runs on the GPU for whole batches of level values; the LP loop of
-estimate_control_amissible_invariant_set (cvxpy / ECOS in the reference, stability.py:7-90) is set-up arithmetic on the
-host, as in the reference, with scipy's LP solver in place of ECOS."""
+check_control_amissible_invariance runs on the GPU for whole batches of level values, and so do the linear programmes of
+estimate_control_amissible_invariant_set (cvxpy / ECOS in the reference, stability.py:7-90): the 2 (nx + nu) programmes the
+loop asks per power of the closed-loop matrix are one launch (mpc_lp_maximize, one wavefront per programme)."""
 from __future__ import annotations
 
 import numpy as np
@@ -51,17 +51,36 @@ def reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu, save_path=
     return Cm
 
 
-def estimate_control_amissible_invariant_set(K, A, B, ubx, ubu, verbose=False, n_limit=1000, save_path=None):
+def lp_maximize_batched(A, b, C, device=None):
+    """max c'x s.t. A x <= b for every row c of C (nlp, d), on the GPU; returns (optima (nlp,), maximisers (nlp, d),
+    status (nlp,): 0 optimum, 1 unbounded, 2 not finished)."""
+    dev = _dev.require_gpu(device)
+    A = np.ascontiguousarray(A, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+    C = np.ascontiguousarray(np.atleast_2d(C), dtype=np.float64)
+    m, d = A.shape
+    if b.shape[0] != m or C.shape[1] != d:
+        raise ValueError("A (m, d), b (m,), C (nlp, d)")
+    Ad, bd, Cd = _dev.f64(A, dev), _dev.f64(b, dev), _dev.f64(C, dev)
+    opt = torch.empty(C.shape[0], dtype=torch.float64, device=dev)
+    xs = torch.empty((C.shape[0], d), dtype=torch.float64, device=dev)
+    st = torch.empty(C.shape[0], dtype=torch.int32, device=dev)
+    rc = _lib.load().mpc_lp_maximize(_dev.stream_ptr(dev), int(C.shape[0]), int(d), int(m), _dev.ptr(Ad), _dev.ptr(bd), _dev.ptr(Cd),
+                                     _dev.ptr(opt), _dev.ptr(xs), _dev.ptr(st))
+    _lib.check(rc, None, "mpc_lp_maximize")
+    return opt.cpu().numpy(), xs.cpu().numpy(), st.cpu().numpy()
+
+
+def estimate_control_amissible_invariant_set(K, A, B, ubx, ubu, verbose=False, n_limit=300, save_path=None, device=None):
     """stability.py:7-90.  Grows the set { x : |phi^k x| <= ubx, |K phi^k x| <= ubu, k = 1..n-1 } (phi = A - B K) one power
     at a time; after each step 2 (len(ubx) + len(ubu)) linear programmes maximise the components of phi^n x / ubx and
-    K phi^n x / ubu (both signs) over the set, and the loop ends when every optimum is below 5e-2 (the reference's test)
-    or n exceeds `n_limit`; the rows are then rebuilt by reconstruct_control_amissible_invariant_set(n, ...).
+    K phi^n x / ubu (both signs) over the set -- one GPU launch for all of them -- and the loop ends when every optimum is
+    below 5e-2 (the reference's test) or n exceeds `n_limit` (the reference's 1000 would need 12000 rows; the kernel
+    takes 4096); the rows are then rebuilt by reconstruct_control_amissible_invariant_set(n, ...).
     Kept as the reference has them: the first power constrained is phi^1, not phi^0 (x itself is never bounded); an
-    unbounded programme counts as +inf and keeps the loop going.  Where the reference catches cvxpy's SolverError and
-    skips the rest of that group of programmes, a programme HiGHS cannot finish is skipped the same way.  The optimum
-    of each programme is HiGHS's instead of ECOS's (interior point, ~1e-8): the stopping index n can differ by one step
-    where an optimum sits within solver tolerance of 5e-2.  Returns the row matrix C (C x <= 1)."""
-    from scipy.optimize import linprog
+    unbounded programme counts as +inf and keeps the loop going; where the reference catches cvxpy's SolverError and
+    skips the rest of that group of programmes, a programme the kernel does not finish skips the rest of its group the
+    same way.  The optimum of each programme is an interior-point optimum like ECOS's (1e-10 relative here): the stopping
+    index n can differ by one step where an optimum sits within solver tolerance of 5e-2.  Returns the rows C (C x <= 1)."""
     K = np.atleast_2d(np.asarray(K, dtype=np.float64)); A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
     ubx = np.asarray(ubx, dtype=np.float64).reshape(-1); ubu = np.asarray(ubu, dtype=np.float64).reshape(-1)
@@ -69,31 +88,24 @@ def estimate_control_amissible_invariant_set(K, A, B, ubx, ubu, verbose=False, n
     phi_np1 = phi.copy()
     rows, rhs = [], []
     n = 1
-
-    def maximise(c):
-        r = linprog(-c, A_ub=np.concatenate(rows), b_ub=np.concatenate(rhs), bounds=(None, None), method="highs")
-        if r.status == 0:
-            return float(-r.fun)
-        if r.status == 3:
-            return float("inf")
-        raise RuntimeError(r.message)
-
     while True:
         M = phi_np1
         rows += [M, -M, K @ M, -(K @ M)]
         rhs += [ubx, ubx, ubu, ubu]
         n += 1
         phi_np1 = phi_np1 @ phi
-        opt_values = []
         groups = [[phi_np1[j] / ubx[j] for j in range(len(ubx))], [(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))],
                   [-phi_np1[j] / ubx[j] for j in range(len(ubx))], [-(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))]]
+        opt, _, status = lp_maximize_batched(np.concatenate(rows), np.concatenate(rhs), np.array([c for g in groups for c in g]), device)
+        opt_values, pos = [], 0
         for group in groups:
-            try:
-                for c in group:
-                    opt_values.append(maximise(c))
-            except RuntimeError as e:
-                if verbose:
-                    print(f"n = {n}: programme not solved ({e}); rest of its group skipped")
+            for k in range(len(group)):
+                if status[pos + k] == 2:
+                    if verbose:
+                        print(f"n = {n}: programme not finished; rest of its group skipped")
+                    break
+                opt_values.append(float("inf") if status[pos + k] == 1 else float(opt[pos + k]))
+            pos += len(group)
         if verbose:
             print(f"n = {n}: optima {opt_values}")
         if np.all(np.array(opt_values) < 5e-2) or n > n_limit:

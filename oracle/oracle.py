@@ -441,6 +441,46 @@ def reconstruct_invariant_set(n, K, A, B, ubx, ubu):
     return C
 
 
+def estimate_invariant_set(K, A, B, ubx, ubu, n_limit=1000):
+    """stability.py:7-90 with scipy's HiGHS in place of cvxpy / ECOS (neither is importable here): the loop's quirks kept
+    (first power constrained is phi^1; stop when every optimum is below 5e-2; an unbounded programme counts as +inf; a
+    programme the solver cannot finish skips the rest of its group).  Returns (C, n, optima of the last round)."""
+    from scipy.optimize import linprog
+    K = np.atleast_2d(np.asarray(K, dtype=np.float64)); A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
+    ubx = np.asarray(ubx, dtype=np.float64).reshape(-1); ubu = np.asarray(ubu, dtype=np.float64).reshape(-1)
+    phi = A - B @ K
+    phi_np1 = phi.copy()
+    rows, rhs = [], []
+    n = 1
+
+    def maximise(c):
+        r = linprog(-c, A_ub=np.concatenate(rows), b_ub=np.concatenate(rhs), bounds=(None, None), method="highs")
+        if r.status == 0:
+            return float(-r.fun)
+        if r.status == 3:
+            return float("inf")
+        raise RuntimeError(r.message)
+
+    while True:
+        M = phi_np1
+        rows += [M, -M, K @ M, -(K @ M)]
+        rhs += [ubx, ubx, ubu, ubu]
+        n += 1
+        phi_np1 = phi_np1 @ phi
+        opt_values = []
+        groups = [[phi_np1[j] / ubx[j] for j in range(len(ubx))], [(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))],
+                  [-phi_np1[j] / ubx[j] for j in range(len(ubx))], [-(K @ phi_np1)[j] / ubu[j] for j in range(len(ubu))]]
+        for group in groups:
+            try:
+                for c in group:
+                    opt_values.append(maximise(c))
+            except RuntimeError:
+                pass
+        if np.all(np.array(opt_values) < 5e-2) or n > n_limit:
+            return reconstruct_invariant_set(n, K, A, B, ubx, ubu), n, opt_values
+
+
 # ---------------------------------------------------------------------------
 # acados emulation (study aid; pins nothing: acados itself cannot run here).  What the reference's solver set-up
 # (LMPC2.py:262-288: SQP, EXACT Hessian, regularize_method MIRROR, MERIT_BACKTRACKING, tol 1e-4, iterate kept between

@@ -52,17 +52,19 @@ def test_checker_solve_with_terminal_rows_satisfies_kkt(prec):
     np.testing.assert_array_equal(a, orc.optimize(cfg, x0, wp, sp)[2])
 
 
-def test_terminal_set_estimate_on_the_host():
-    """estimate_control_amissible_invariant_set with the L controller's (K, A, B): rows = 2 (5 + 1) per power of the
-    closed loop, equal to reconstruct_control_amissible_invariant_set at the stopping index, and the polytope is what the
+def test_checker_invariant_set_loop():
+    """The checker's restatement of estimate_control_amissible_invariant_set (scipy's LP solver; the library runs the
+    programmes on the GPU and is compared with this loop in the GPU tests) with the L controller's (K, A, B): rows =
+    2 (5 + 1) per power of the closed loop, equal to the reconstruction at the stopping index, and the polytope is what the
     loop's test says: every point of it keeps the state and input constraints for the next steps of x+ = (A - B K) x."""
+    from oracle import oracle as O
     from mpc_amd.controllers import LOcp
     from mpc_amd import stability as S
     ctl = LOcp(50, 0.5, _host_only=True)
-    C = ctl.terminal_set_estimate()
-    assert C is ctl.terminal_set_estimate()                  # computed once
     A, B, K = ctl.A_stability.astype(np.float64), ctl.B_stability.astype(np.float64), ctl.K
     ubx = np.array([100, 100, 100, 100, ctl.max_steering]); ubu = np.array([ctl.max_steering_rate])
+    C, n_stop, _ = O.estimate_invariant_set(K, A, B, ubx, ubu)
+    assert n_stop == C.shape[0] // 12 - 1
     assert C.shape[1] == 5 and C.shape[0] % 12 == 0
     n = C.shape[0] // 12 - 1
     assert 2 <= n <= 1000

@@ -228,3 +228,74 @@ def test_auto_layout_handle_moves_to_the_stage_wise_solver(orc64):
     torch.cuda.synchronize()
     assert torch.equal(Ua, Ub) and torch.equal(ta, tb) and torch.equal(sa, sb)
     assert not torch.equal(Ua, U0)                             # the rows are active somewhere
+
+
+def test_batched_linear_programmes_match_highs():
+    """mpc_lp_maximize against scipy's HiGHS on random bounded programmes (1 to 6 unknowns, 8 to 600 rows, the origin
+    inside or outside the feasible set) and on an unbounded one."""
+    from scipy.optimize import linprog
+    from mpc_amd.stability import lp_maximize_batched
+    rng = np.random.default_rng(17)
+    for d, m in [(1, 8), (2, 30), (3, 64), (5, 84), (5, 600), (6, 257)]:
+        A = rng.standard_normal((m, d))
+        x_in = rng.standard_normal(d) * (0.0 if m % 2 else 1.0)              # a point strictly inside
+        b = A @ x_in + rng.uniform(0.1, 2.0, m)
+        A = np.vstack([A, np.eye(d), -np.eye(d)]); b = np.concatenate([b, x_in + 50.0, 50.0 - x_in])   # bounded
+        C = rng.standard_normal((24, d))
+        opt, xs, st = lp_maximize_batched(A, b, C)
+        assert (st == 0).all(), (d, m, st)
+        for q in range(C.shape[0]):
+            r = linprog(-C[q], A_ub=A, b_ub=b, bounds=(None, None), method="highs")
+            assert r.status == 0
+            assert opt[q] == pytest.approx(-r.fun, rel=1e-8, abs=1e-8), (d, m, q)
+            assert (A @ xs[q] <= b + 1e-8).all() and C[q] @ xs[q] == pytest.approx(opt[q], rel=1e-12, abs=1e-12)
+    A = np.array([[1.0, 0.0], [-1.0, 0.0], [0.0, -1.0]]); b = np.ones(3)           # open towards +y
+    opt, xs, st = lp_maximize_batched(A, b, np.array([[0.0, 1.0], [1.0, 0.0]]))
+    assert st[0] == 1 and st[1] == 0 and opt[1] == pytest.approx(1.0, abs=1e-9)
+
+
+def test_invariant_set_loop_on_the_gpu_matches_checker_loop():
+    """estimate_control_amissible_invariant_set (stability.py:7-90) with its linear programmes on the GPU.  For a gain of
+    ordinary size the loop stops at the same index with the same rows as the checker's loop with scipy's LP solver.  With
+    the reference's own gain (LMPC2.py:433-449: R' = 0 makes K ~ 1e4, the rows' condition number 1e17) the outcome of the
+    loop is decided by which programmes the LP solver gives up on (the reference skips those, stability.py:43-76): the
+    optima are compared where both solvers finish, and the rows LOcp.terminal_set_estimate() hands out are checked for
+    what they are, the set whose points keep the state and input bounds over the next n steps."""
+    from scipy.optimize import linprog
+    from oracle import oracle as O
+    from mpc_amd.controllers import LOcp
+    from mpc_amd import stability as S
+    ctl = LOcp(50, 0.5)
+    A, B, K = ctl.A_stability.astype(np.float64), ctl.B_stability.astype(np.float64).reshape(5, 1), np.atleast_2d(ctl.K)
+    ubx = np.array([100, 100, 100, 100, ctl.max_steering]); ubu = np.array([ctl.max_steering_rate])
+    import scipy.linalg
+    P2 = scipy.linalg.solve_discrete_are(A, B, np.diag([1e3, 1.0, 0.1, 0.1, 1.0]), np.array([[1.0]]))
+    K2 = np.linalg.solve(B.T @ P2 @ B + 1.0, B.T @ P2 @ A)
+    ubx2 = np.array([2.0, 0.5, 3.0, 3.0, 0.3])
+    C2_ref, n2, _ = O.estimate_invariant_set(K2, A, B, ubx2, ubu, n_limit=200)
+    C2 = S.estimate_control_amissible_invariant_set(K2, A, B, ubx2, ubu, n_limit=200)
+    assert C2.shape == C2_ref.shape and np.array_equal(C2, C2_ref) and n2 > 3
+    # the reference's gain: first two rounds of programmes, which both solvers finish
+    phi = A - B @ K; p1 = phi.copy(); rows, rhs = [], []
+    for n in (2, 3):
+        rows += [p1, -p1, K @ p1, -(K @ p1)]; rhs += [ubx, ubx, ubu, ubu]
+        p1 = p1 @ phi
+        Cn = np.array([p1[j] / ubx[j] for j in range(5)] + [(K @ p1)[0] / ubu[0]])
+        Am, bm = np.concatenate(rows), np.concatenate(rhs)
+        opt, xs, st = S.lp_maximize_batched(Am, bm, Cn)
+        assert (st == 0).all()
+        for q in range(6):
+            r = linprog(-Cn[q], A_ub=Am, b_ub=bm, bounds=(None, None), method="highs")
+            assert r.status == 0 and opt[q] == pytest.approx(-r.fun, rel=1e-5, abs=1e-9), (n, q)
+    C = ctl.terminal_set_estimate()
+    assert C is ctl.terminal_set_estimate()                  # computed once
+    n = C.shape[0] // 12 - 1
+    assert C.shape[1] == 5 and C.shape[0] % 12 == 0 and n >= 2
+    np.testing.assert_array_equal(C, S.reconstruct_control_amissible_invariant_set(n, K, A, B, ubx, ubu))
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((200, 5)) * np.array([0.5, 0.1, 1.0, 1.0, 0.05])
+    pts *= (rng.uniform(0.2, 1.0, 200) / (pts @ C.T).max(axis=1))[:, None]
+    x = pts.T
+    for _ in range(min(n, 8)):
+        assert (np.abs(x) <= ubx[:, None] * (1 + 1e-9)).all() and (np.abs(K @ x) <= ubu[:, None] * (1 + 1e-9)).all()
+        x = phi @ x
