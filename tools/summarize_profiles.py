@@ -13,6 +13,23 @@ dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 tag = sys.argv[3] if len(sys.argv) > 3 else "r01b"
 os.makedirs(dst, exist_ok=True)
 traffic = {}
+# Registers and scratch come from the compiler's report on the shipped code object (tools/kernel_resources.py), matched
+# by kernel name: rocprofv3's own register columns count allocation granules and came out at half those figures.
+res = {}
+res_csv = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"{tag}_kernel_resources.csv")
+if os.path.exists(res_csv):
+    for r in csv.DictReader(open(res_csv)):
+        res["".join(r["kernel"].split())] = r
+
+
+def resources(name):
+    key = "".join(name.split())
+    for k, r in res.items():
+        if k == key or k.startswith(key) or key.startswith(k.split("(")[0].replace("void", "")):
+            return [r["vgpr"], r["agpr"], r["sgpr"], r["scratch_bytes_per_lane"]]
+    return ["", "", "", ""]
+
+
 for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
     name = os.path.basename(os.path.dirname(db))
     con = sqlite3.connect(db)
@@ -22,10 +39,11 @@ for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
         "from kernels group by name order by sum(duration) desc").fetchall()
     with open(os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "vgpr", "agpr", "sgpr", "lds_bytes",
-                    "scratch_bytes", "grid_x", "workgroup_x"])
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "vgpr", "agpr", "sgpr", "scratch_bytes_per_lane",
+                    "lds_bytes", "grid_x", "workgroup_x"])
         for r in rows[:12]:
-            w.writerow([r[0][:120]] + [int(v) if v is not None else "" for v in r[1:]])
+            iv = [int(v) if v is not None else "" for v in r[1:]]
+            w.writerow([r[0][:120]] + iv[:5] + resources(r[0]) + [iv[8], iv[10], iv[11]])
     pmc = con.execute("select count(*) from pmc_events").fetchone()[0]
     if pmc:
         cols = [r[1] for r in con.execute("pragma table_info('counters_collection')")]
@@ -40,6 +58,8 @@ for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
         # HBM bytes of the timed launch: the MPC kernel dispatches in order are [settling launch (c2 only)], warm-up,
         # timed region, ...; FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950 tallies reads at half their size
         kind, wl = name[3], name[5:]
+        if kind not in "fw":
+            continue
         disp = con.execute("select dispatch_id, sum(value), max(duration) from counters_collection where kernel_name like '%k_mpc%' "
                            "group by dispatch_id order by dispatch_id").fetchall()
         idx = 2 if wl == "c2_driver" else 1
@@ -50,7 +70,8 @@ for db in sorted(glob.glob(os.path.join(src, "*", "*_results.db"))):
 
 if traffic:
     import json
-    keys = {"c2_driver": "c2:B=4096:steps=20:warmup=5", "c2_default": "c2:B=4096:steps=1000:warmup=50", "c3": "c3:B=8192:steps=100:warmup=10"}
+    keys = {"c2_driver": "c2:B=4096:steps=20:warmup=5", "c2_default": "c2:B=4096:steps=1000:warmup=50", "c3": "c3:B=8192:steps=100:warmup=10",
+            "c4": "c4:B=8192:steps=300:warmup=20", "c5": "c5:B=131072:steps=50:warmup=5"}
     out = {}
     for wl, t in traffic.items():
         if "fetch_bytes" in t and "write_bytes" in t:
