@@ -55,7 +55,7 @@ def test_emulated_closed_loop_matches_checker_emulation(orc80, kind, N, Tf):
         total_sqp += sum(sqp)
     assert stats["sum_sqp_iterations"] == total_sqp              # the same number of SQP steps, call by call
     assert (sim.status.cpu().numpy() == 0).all()
-    # and it is not the minimiser: the same loops without the emulation differ by what DESIGN quantifies (~1e-3 rad/s)
+    # and it is not the minimiser: the same loops without the emulation differ by ~1e-3 rad/s, the distance of the regularised SQP step from the minimiser
     plain = SkidpadBatch(N, Tf, starts, model=kind)
     _, up = plain.run(nsteps, record=True)
     diff = np.abs(up.cpu().numpy() - us).max()
