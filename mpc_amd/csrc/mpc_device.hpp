@@ -160,7 +160,9 @@ __device__ __forceinline__ void plant_rk4_c(double *x, double u, double dt, cons
     for (int i = 0; i < NX; i++) t[i] = x[i] + dt * k3[i];
     plant_f_c<NX>(t, u, c, k4);
 #pragma unroll
-    for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+    // (the reference divides by 6; the product with 1/6 differs from that by at most one unit in the last place of the
+    // increment, and a double-precision division is a dozen instructions per state on a path that is issue-bound)
+    for (int i = 0; i < NX; i++) x[i] = x[i] + dt * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (1.0 / 6.0);
 }
 
 template <int NX>
@@ -282,6 +284,34 @@ __device__ __forceinline__ void sk_pose(double q, double *o)
         if (q - SK_CENTER >= 2 * SK_LAP) { o[0] = SK_CENTER + sb * SK_R; o[1] = SK_R - cb * SK_R; o[2] = cb; o[3] = sb; }
         else { o[0] = SK_CENTER + sb * SK_R; o[1] = -SK_R + cb * SK_R; o[2] = cb; o[3] = -sb; }
     } else { o[0] = q; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+}
+
+// sk_pose with the sine and cosine of b = (q - centre) / r handed in.
+__device__ __forceinline__ void sk_pose_sc(double q, double sb, double cb, double *o)
+{
+    if (q - SK_CENTER >= 4 * SK_LAP) { o[0] = q - 4 * SK_LAP; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+    else if (q - SK_CENTER > 0) {
+        if (q - SK_CENTER >= 2 * SK_LAP) { o[0] = SK_CENTER + sb * SK_R; o[1] = SK_R - cb * SK_R; o[2] = cb; o[3] = sb; }
+        else { o[0] = SK_CENTER + sb * SK_R; o[1] = -SK_R + cb * SK_R; o[2] = cb; o[3] = -sb; }
+    } else { o[0] = q; o[1] = 0.0; o[2] = 1.0; o[3] = 0.0; }
+}
+
+// Cosine and sine of b0 = (p0 - centre) / r for the progress p0 = sk_pos2progress(x, y, lap).  On the circles p0 is an
+// arctangent of the car's position about the circle's centre, so the pair is that position's direction (with the signs
+// of the lap's formula) and needs no trigonometric function; elsewhere sincos.  The waypoints ahead are this pair turned
+// by the fixed angles of their distances (the fused step loops keep those turns in a table per scenario), which agrees
+// with evaluating sincos per waypoint to a few units in the last place.
+__device__ __forceinline__ void sk_progress_sincos(double x, double y, int lap, double p0, double &c0, double &s0)
+{
+    double X = 0.0, Y = 0.0, sgn = 1.0;
+    if (lap > 0 && lap < 3) { X = x - SK_CENTER; Y = -SK_R - y; }                   // b0 = pi - atan2(X, Y) + 2 pi (lap - 1)
+    else if (lap > 2 && lap < 5) { X = SK_CENTER - x; Y = y - SK_R; sgn = -1.0; }   // b0 = pi + atan2(X, Y) + 2 pi (lap - 1)
+    const double n2 = X * X + Y * Y;
+    if (n2 > 0.0) {
+        const double rn = 1.0 / sqrt(n2);
+        c0 = -Y * rn; s0 = sgn * X * rn;
+    } else
+        sincos((p0 - SK_CENTER) / SK_R, &s0, &c0);
 }
 
 // utils/step_planning.py:63-80: a unit step in y at progress 0, reached over `ramp` metres of progress (ramp_length;

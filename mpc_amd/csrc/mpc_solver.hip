@@ -191,7 +191,10 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
 // for the closed-loop statistics the step's value for each of them (PARK_CL + i: see cl_step)
 constexpr int PARK_CL = 20;
 constexpr int PARK_W = PARK_CL + CL_STAT_W;
-template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W; }
+// and, for the skidpad planner, cosine and sine of the angle each waypoint lies ahead of the first on the circles
+// ([2][N+1], fixed per scenario: the target speed and the time step are)
+template <int N> constexpr int wave_rot_doubles() { return 2 * (N + 1); }
+template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W + wave_rot_doubles<N>(); }
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
 constexpr int FIXED_WPB = 4;
 
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
     double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
+    double *s_rot = wbase + 4 * (N + 1) + N * STAGE_W + PARK_W;   // skidpad planner: cos / sin of the waypoints' angles ahead
     double *s_park = wbase + 4 * (N + 1) + N * STAGE_W;   // plant state [10], plant coefficients [7], planner memory and speed while a step's solve runs
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
@@ -324,6 +328,13 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     if (a.mode != MODE_SOLVE && a.accumulate && lane < CL_STAT_W) cl_acc = a.stat_out[STAT_W * (size_t)s + STAT_CL + lane];
     if (lane < CL_STAT_W) s_park[PARK_CL + lane] = lane == CL_STEPS ? 1.0 : 0.0;
     const double cs0 = speed_cumsum(tvel, lane), cs1 = (lane + WAVE <= N) ? speed_cumsum(tvel, lane + WAVE) : 0.0;
+    if (a.mode == MODE_SKIDPAD) {
+        for (int k = lane; k <= N; k += WAVE) {
+            double sk, ck;
+            sincos(((k < WAVE ? cs0 : cs1) * dt) / SK_R, &sk, &ck);
+            s_rot[k] = ck; s_rot[(N + 1) + k] = sk;
+        }
+    }
     double *warm_rec = (a.ipm_ws && a.mode != MODE_SOLVE) ? a.ipm_ws + (size_t)s * IPM_WARM_DOUBLES : nullptr;
     bool warm_ok = warm_rec && warm_rec[5 * WAVE] == 1.0;
     const int nsteps = (a.mode == MODE_SOLVE) ? 1 : a.nsteps;
@@ -356,12 +367,14 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 xh3 = s_xe[5]; xh4 = s_xe[6]; xh5 = s_xe[7]; dhat = s_xe[9];
             }
             double p0;
+            double c0 = 1.0, s0 = 0.0;                                     // cos / sin of the first waypoint's angle (skidpad)
             if (a.mode == MODE_SKIDPAD) {
                 int lp = lapv;
                 p0 = sk_pos2progress(px, py, lp);
                 if (prevp > p0 + 2 * SK_R) { lp += 1; p0 = sk_pos2progress(px, py, lp); }
                 if (lp < 0 || lp > 7) lap_flag = 5;      // the reference switches to its speed profile there (path_planning.py:241-248)
                 prevp = p0;                                                // path_planning.py:251
+                sk_progress_sincos(px, py, lp, p0, c0, s0);
             } else
                 p0 = px;                                                   // step_planning.py:83-86
             double ch, sh;                                                 // skidpad_simulator.py:104, path_planning.py:253
@@ -369,7 +382,10 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             for (int k = lane; k <= N; k += WAVE) {
                 double o[4];
                 const double q = (k == 0) ? p0 : p0 + (k < WAVE ? cs0 : cs1) * dt;    // path_planning.py:236-240
-                if (a.mode == MODE_SKIDPAD) sk_pose(q, o);
+                if (a.mode == MODE_SKIDPAD) {
+                    const double ck = s_rot[k], sk = s_rot[(N + 1) + k];
+                    sk_pose_sc(q, s0 * ck + c0 * sk, c0 * ck - s0 * sk, o);
+                }
                 else step_pose(q, a.step_ramp, o);
                 to_car_frame(o, px, py, ch, sh);
                 s_ref[k] = o[0]; s_ref[(N + 1) + k] = o[1]; s_ref[2 * (N + 1) + k] = o[3];

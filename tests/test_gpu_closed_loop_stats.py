@@ -26,7 +26,8 @@ def _check(st, cl, steps=STEPS, cost_rtol=1e-6, pred=False):
     assert st["sum_input_sq"] == pytest.approx(cl[:, 3].sum(), rel=1e-5)
     # | |(cos, sin)| - 1 | is a few ulp of 1: double precision evaluates it to +-2.2e-16 per step
     assert st["sum_heading_pair_violation"] == pytest.approx(cl[:, 2].sum(), abs=3e-16 * n * steps)
-    assert st["max_heading_pair_violation"] == pytest.approx(cl[:, 5].max(), abs=5e-16)
+    # (where the plant's integration error shows in the pair, ~1e-9 at 15 m/s, it follows the states' agreement instead)
+    assert st["max_heading_pair_violation"] == pytest.approx(cl[:, 5].max(), abs=5e-16, rel=1e-6)
     assert st["max_bound_violation"] == pytest.approx(max(cl[:, 4].max(), 0.0), abs=1e-9)
     if pred:
         assert st["max_predicted_heading_pair_violation"] == pytest.approx(cl[:, 6].max(), abs=1e-12)
