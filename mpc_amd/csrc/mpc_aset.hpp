@@ -9,9 +9,10 @@
 //   U = Uu - inv(H) E' nu,     (E inv(H) E') nu = E Uu - b,
 // an m x m positive definite system whose entries are read from the table T = [I; P] inv(H) [I P'] (P = the steering
 // rows), 2N x 2N, symmetric.  The set is found by exchanging bounds (per iteration the bound whose multiplier has the
-// wrong sign by the most leaves, the bound the new point violates by the most enters) started from the previous
-// closed-loop step's set moved one stage ahead; when nothing is left to exchange the KKT conditions hold, i.e. U is
-// the unique minimiser.  The result is then refined through the same factorisation (what it misses its active bounds
+// wrong sign by the most leaves, the bound the new point violates by the most enters) started from a prediction of
+// the set out of the previous two closed-loop steps' solves (aset_predict; the previous step's set moved one stage
+// ahead when only one is at hand); when nothing is left to exchange the KKT conditions hold, i.e. U is the unique
+// minimiser.  The result is then refined through the same factorisation (what it misses its active bounds
 // by) and certified by the size of that correction; optionally the correction is the Newton step computed from H
 // itself (ASET_CERT_FROM_H).  Whatever does not end that way within a few iterations (sets larger than the capacity,
 // a cycling iteration) is left to the interior point.
@@ -212,6 +213,51 @@ __device__ __forceinline__ double aset_steer_multiplier(int lane, int ad, bool i
 
 enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 };
 
+// History of a scenario's solves behind its warm-start record (the record itself: [5][WAVE] inputs and multipliers, a
+// validity flag and two back-off counters): two slots of [4][WAVE] doubles -- signed multipliers of the input and of
+// the steering bounds (positive at the upper bound, zero where the bound is not active), and the distance of every
+// input and steering angle from its nearer bound relative to the bound -- for the last two steps this method solved
+// in a row, and one word `hist` = depth | newest slot << 2 (depth 0: the slots say nothing, 1: the newest describes the
+// previous step, 2: the other one the step before it as well).
+constexpr int ASET_HIST_WORD = 5 * WAVE + 3;
+constexpr int ASET_HIST_BASE = 5 * WAVE + 8;
+constexpr int ASET_HIST_SLOT = 4 * WAVE;
+
+// What one row (a bound of stage i) does at the next step, judged in one frame of reference from its state at the last
+// two steps there: +-1 stays active on that side, 0 inactive, 2 becomes active.  nu: signed multiplier (0 = not
+// active), s: distance from the bound; _t the previous step, _p the one before.  An active row's multiplier and an
+// inactive row's distance are continued linearly; a row that has just changed keeps its new state.
+__device__ __forceinline__ int aset_continue(double nu_t, double s_t, double nu_p, double s_p)
+{
+    const int a_t = nu_t > 0.0 ? 1 : (nu_t < 0.0 ? -1 : 0), a_p = nu_p > 0.0 ? 1 : (nu_p < 0.0 ? -1 : 0);
+    if (a_t != 0) return (a_p != a_t || (2.0 * nu_t - nu_p) * (double)a_t > 0.0) ? a_t : 0;
+    return (a_p == 0 && !(2.0 * s_t - s_p > 0.0)) ? 2 : 0;
+}
+
+// The set the next solve starts from, for one kind of bound (input or steering; `last` = its last stage), out of the
+// two history slots `cur` (previous step) and `prv` (the step before): nu / s arrays of one kind, WAVE apart as laid
+// out above.  Between two closed-loop steps the solution moves one stage ahead where it follows the plan, and stays
+// where it is tied to the end of the horizon; most ends of a run of active bounds do something in between.  A row
+// inside a run or far from one is the same in both frames; at the end of a run the row is taken as active when both
+// frames -- row i continued from (i+1, i+2) of the last two steps, and from (i, i) -- say so.  A wrong guess costs an
+// exchange iteration, nothing else.
+__device__ __forceinline__ int aset_predict(const aset_gdouble *cur_nu, const aset_gdouble *cur_s, const aset_gdouble *prv_nu,
+                                            const aset_gdouble *prv_s, int lane, int last)
+{
+    const int i0 = min(lane, last), i1 = min(lane + 1, last), i2 = min(lane + 2, last);
+    const bool in1 = lane + 1 <= last, in2 = lane + 2 <= last;
+    // (all twelve requests go out before the first is used)
+    const double nt_x = cur_nu[i0], st_x = cur_s[i0], np_x = prv_nu[i0], sp_x = prv_s[i0];
+    double nt_t = cur_nu[i1], st_t = cur_s[i1], np_t = prv_nu[i2], sp_t = prv_s[i2];
+    if (!in1) { nt_t = 0.0; st_t = 1.0; }
+    if (!in2) { np_t = 0.0; sp_t = 1.0; }
+    const int A = nt_t > 0.0 ? 1 : (nt_t < 0.0 ? -1 : 0), B = nt_x > 0.0 ? 1 : (nt_x < 0.0 ? -1 : 0);
+    if (A == B) return A;
+    const int pa = aset_continue(nt_t, st_t, np_t, sp_t), pb = aset_continue(nt_x, st_x, np_x, sp_x);
+    if (pa == 0 || pb == 0) return 0;
+    return pa != 2 ? pa : (A != 0 ? A : B);
+}
+
 struct AsetResult {
     double U;          // the minimiser (this lane's input), valid when why == ASET_SOLVED
     int au, ad;        // this lane's input / steering bound in the set: +1 upper, -1 lower, 0 none
@@ -226,13 +272,14 @@ struct AsetResult {
 // minimiser (0 beyond the horizon), vdu = dt * prefix sum of Uu; up_d / lo_d: this lane's steering bounds
 // (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
 // ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
-// written with the result when the solve succeeds (or NULL); lds: the wave's 4 (N + 1) doubles of references and speeds.
+// written with the result when the solve succeeds, together with the history slot and word `hist` names (or NULL); lds:
+// the wave's 4 (N + 1) doubles of references and speeds.
 // Inlined into the caller's one non-inlined function of the constrained step (solve_constrained in mpc_solver.hip), whose
 // registers stay out of the per-step path's allocation.
 template <int N, int MM>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
-                                                double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large)
+                                                double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist)
 {
     constexpr unsigned LD = 2 * N;                       // row length of T
     const bool valid = lane < N, validd = lane < N - 1;
@@ -434,11 +481,20 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     U = valid ? fmin(fmax(U, -umax), umax) : 0.0;
     if (rec && valid) {
         aset_gdouble *w = (aset_gdouble *)rec;
+        const double pu = au > 0 ? fmax(nu_u, 0.0) : 0.0, mu = au < 0 ? fmax(-nu_u, 0.0) : 0.0;
+        const double pd = ad > 0 ? fmax(nu_d, 0.0) : 0.0, md = ad < 0 ? fmax(-nu_d, 0.0) : 0.0;
         w[lane] = U;
-        w[WAVE + lane] = au > 0 ? fmax(nu_u, 0.0) : 0.0;
-        w[2 * WAVE + lane] = au < 0 ? fmax(-nu_u, 0.0) : 0.0;
-        w[3 * WAVE + lane] = ad > 0 ? fmax(nu_d, 0.0) : 0.0;
-        w[4 * WAVE + lane] = ad < 0 ? fmax(-nu_d, 0.0) : 0.0;
+        w[WAVE + lane] = pu;
+        w[2 * WAVE + lane] = mu;
+        w[3 * WAVE + lane] = pd;
+        w[4 * WAVE + lane] = md;
+        aset_gdouble *hs = w + ASET_HIST_BASE + ((hist >> 2) & 1) * ASET_HIST_SLOT;
+        const double vdf = dt * incl_prefix(U, lane);
+        hs[lane] = pu - mu;
+        hs[WAVE + lane] = pd - md;
+        hs[2 * WAVE + lane] = (umax - fabs(U)) / umax;
+        hs[3 * WAVE + lane] = fmin(up_d - vdf, vdf - lo_d) / dmax;
+        if (lane == 0) w[ASET_HIST_WORD] = (double)hist;
     }
     out.U = U; out.why = ASET_SOLVED;
     return out;
@@ -450,8 +506,8 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 #define ASET_CLASS_LINKAGE __forceinline__
 #endif
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
-                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large
-#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large
+                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist
+#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large, hist
 template <int N, int MM, int TAG>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_small(MPC_ASET_ARGS)
 {
@@ -475,18 +531,28 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_full(MPC_ASET_ARGS)
 #undef MPC_ASET_ARGS
 #undef MPC_ASET_PASS
 
-// One solve: the starting set (the previous step's set one stage ahead when rec_valid, else what the unconstrained
-// minimiser violates), then the iteration in the smallest size class that holds the set, moving up a class when the set
-// outgrows it.  Arguments as aset_body.
+// One solve: the starting set (aset_predict when rec_valid and the record's history `hist_in` holds two steps, the
+// previous step's set one stage ahead when rec_valid, else what the unconstrained minimiser violates), then the
+// iteration in the smallest size class that holds the set, moving up a class when the set outgrows it.  Arguments as
+// aset_body.
 template <int N, int TAG>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
-                                                       double *rec, bool rec_valid, double *lds, int cap_large)
+                                                       double *rec, bool rec_valid, double *lds, int cap_large, int hist_in)
 {
     constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3);
     const bool valid = lane < N, validd = lane < N - 1;
     int au = 0, ad = 0;
-    if (rec_valid) {
+    // the history after this solve: one step more when the previous step was solved here too, else this step alone
+    const bool chain = rec_valid && (hist_in & 3) != 0;
+    const int cur = (hist_in >> 2) & 1;
+    const int hist = chain ? (min((hist_in & 3) + 1, 2) | ((cur ^ 1) << 2)) : 1;
+    if (chain && (hist_in & 3) == 2) {
+        const aset_gdouble *hc = (const aset_gdouble *)rec + ASET_HIST_BASE + cur * ASET_HIST_SLOT;
+        const aset_gdouble *hp = (const aset_gdouble *)rec + ASET_HIST_BASE + (cur ^ 1) * ASET_HIST_SLOT;
+        au = aset_predict(hc, hc + 2 * WAVE, hp, hp + 2 * WAVE, lane, N - 1);
+        ad = aset_predict(hc + WAVE, hc + 3 * WAVE, hp + WAVE, hp + 3 * WAVE, lane, N - 2);
+    } else if (rec_valid) {
         const aset_gdouble *w = (const aset_gdouble *)rec;
         const int lc = valid ? lane : 0;
         const int ln = min(lc + 1, N - 1), lnd = min(lc + 1, N - 2);
@@ -503,18 +569,18 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
     int m = __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0));
     if (!rec_valid && m > ASET_COLD_MAX) return r;       // a large violated set says little about the active one
-    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
+    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     if (C1 > C0 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
+        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
+        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C3 > C2 && r.why == ASET_GROW) {
         m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
-        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large);
+        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     return r;
 }

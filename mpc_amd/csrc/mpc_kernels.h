@@ -13,7 +13,7 @@ namespace mpc {
 
 constexpr int STAT_W = 20;                 // doubles per scenario in SolveArgs::stat_out (4 solver values, CL_STAT_W closed-loop statistics, spare)
 constexpr int STAT_CL = 4;                 // where the closed-loop statistics start in that record
-constexpr int IPM_WARM_DOUBLES = 6 * 128;  // interior-point warm-start record per scenario (see IpmParams); the any-horizon
+constexpr int IPM_WARM_DOUBLES = 7 * 128;  // interior-point warm-start record per scenario (see IpmParams); the any-horizon
                                            // kernel keeps [5][128] and its flag at 5 * 128, the register kernels [5][64] and 5 * 64
 
 enum { MODE_SOLVE = 0, MODE_SKIDPAD = 1, MODE_STEP = 2, MODE_OFL = 3 };   // OFL: step planner on the EKF estimate

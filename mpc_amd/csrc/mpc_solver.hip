@@ -149,14 +149,18 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
     // as many active bounds as inputs) tries the method again only after 1, 3, 7, 15 steps of interior point alone.  The
     // two counters (steps to wait, failures in a row) travel in the scenario's record behind its validity flag.
     gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
-    double bo0 = 0.0, bo1 = 0.0;
-    if (bo) { bo0 = bo[0]; bo1 = bo[1]; }                                       // one round trip for both
+    double bo0 = 0.0, bo1 = 0.0, bo2 = 0.0;
+    if (bo) { bo0 = bo[0]; bo1 = bo[1]; bo2 = bo[2]; }                          // one round trip for all (bo[2]: the history word of the active-set solve)
+    // (the output-feedback loop's sets follow the estimate's noise, not the plan: its solves start from the previous set
+    // moved one stage ahead, measured quicker there than the prediction from two steps)
+    const int hist_raw = __builtin_amdgcn_readfirstlane((int)bo2);
+    const int hist = as_cap_large == ASET_CAP_LARGE_NOISY ? ((hist_raw & ~3) | min(hist_raw & 3, 1)) : hist_raw;
     const int wait = __builtin_amdgcn_readfirstlane((int)bo0);                  // wave-uniform
     if (T && wait > 0) {
         if (lane == 0) bo[0] = (double)(wait - 1);
     } else if (T) {
         const AsetResult r = active_set_solve<N, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
-                                                      prm.warm_mode != 0, lds, as_cap_large);
+                                                      prm.warm_mode != 0, lds, as_cap_large, hist);
         out.work = r.iters;
         // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
         // registers of the step loop they would crowd the unconstrained steps.  (Atomics without a return value: nothing
@@ -170,6 +174,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
             const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
             if ((double)streak != bo1) bo[1] = (double)streak;
             if (streak) bo[0] = (double)((1 << streak) - 1);
+            if (r.why != ASET_SOLVED && hist != 0) bo[2] = 0.0;          // the record will be the interior point's: no history
         }
         if (r.why == ASET_SOLVED) {
             out.U = r.U; out.warm_valid = prm.warm != nullptr;
@@ -194,7 +199,7 @@ constexpr int PARK_W = PARK_CL + CL_STAT_W;
 // and, for the skidpad planner, cosine and sine of the angle each waypoint lies ahead of the first on the circles
 // ([2][N+1], fixed per scenario: the target speed and the time step are)
 template <int N> constexpr int wave_rot_doubles() { return 2 * (N + 1); }
-template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W + wave_rot_doubles<N>(); }
+template <int N> constexpr int wave_lds_doubles() { return 4 * (N + 1) + N * STAGE_W + PARK_W; }
 // fixed-model-only variant, shared by the 4 waves of a workgroup: ncomp reference maps + 5 state/offset maps
 constexpr int FIXED_WPB = 4;
 
@@ -221,12 +226,12 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
     const int ncomp = __popc(a.sh_mask & 7);
     double *s_K = lds;
     double *s_Kx = lds + (GENERAL ? 0 : ncomp * N * N);
-    const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+    const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : wave_rot_doubles<N>());
     double *wbase = GENERAL ? lds : s_Kx + 5 * N + wave * wave_area;
     double *s_ref = wbase, *s_p = wbase + 3 * (N + 1), *s_stage = wbase + 4 * (N + 1);
-    double *s_rot = wbase + 4 * (N + 1) + N * STAGE_W + PARK_W;   // skidpad planner: cos / sin of the waypoints' angles ahead
     double *s_park = wbase + 4 * (N + 1) + N * STAGE_W;   // plant state [10], plant coefficients [7], planner memory and speed while a step's solve runs
     double *s_ekf = wbase + wave_lds_doubles<N>();     // MODE_OFL only: xe[10] P[100] F[100] T[100] Aug[119]
+    double *s_rot = wbase + wave_lds_doubles<N>();     // every other mode: the skidpad planner's cos / sin of the waypoints' angles ahead (the two loops never run together)
     double *s_wv = GENERAL ? wbase + wave_area : nullptr;
     double *s_We = GENERAL ? s_wv + 6 * N : nullptr;
     double *s_ref6 = EMUL ? s_We + 36 : nullptr;          // EMUL: the references the regularised problem is condensed with, [6][N+1]
@@ -847,7 +852,7 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
 {
     if (a.sh_H && a.sh_exclusive) {
         const int ncomp = __builtin_popcount(a.sh_mask & 7);
-        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : wave_rot_doubles<N>());
         const size_t lds = sizeof(double) * (size_t)(ncomp * N * N + 5 * N + FIXED_WPB * wave_area);
         static bool lds_ok[MPC_MAX_DEVICES] = {}, lds_ok_pull[MPC_MAX_DEVICES] = {};
         if (hipError_t e = a.queue ? allow_big_lds(reinterpret_cast<const void *>(&k_mpc<N, false, true>), lds_ok_pull)
@@ -873,7 +878,7 @@ static hipError_t launch_n(const DevCfg &cfg, const SolveArgs &a, hipStream_t st
         if (a.queue) hipLaunchKernelGGL((k_mpc<N, false, true>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
         else hipLaunchKernelGGL((k_mpc<N, false, false>), dim3(blocks), dim3(FIXED_WPB * WAVE), lds, st, cfg, a);
     } else {
-        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : 0);
+        const int wave_area = wave_lds_doubles<N>() + (a.mode == MODE_OFL ? EKF_LDS : wave_rot_doubles<N>());
         const size_t lds = sizeof(double) * (size_t)(wave_area + 6 * N + 36 + (a.sqp_x ? 6 * (N + 1) : 0));
         if (a.sqp_x) hipLaunchKernelGGL((k_mpc<N, true, false, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
         else hipLaunchKernelGGL((k_mpc<N, true>), dim3(a.B), dim3(WAVE), lds, st, cfg, a);
