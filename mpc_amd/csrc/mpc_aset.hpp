@@ -8,7 +8,15 @@
 // input bound, dt * prefix-sum row for a steering bound), the minimiser on that set is
 //   U = Uu - inv(H) E' nu,     (E inv(H) E') nu = E Uu - b,
 // an m x m positive definite system whose entries are read from the table T = [I; P] inv(H) [I P'] (P = the steering
-// rows), 2N x 2N, symmetric.  The set is found by exchanging bounds (per iteration the bound whose multiplier has the
+// rows), 2N x 2N, symmetric.
+// Most rows of a large set fix one input each (an input at its rate bound; inside a run of active steering bounds, the
+// input between two of them): with F the fixed inputs, R the free ones and P the remaining steering rows, the same
+// point solves the bordered system in the free inputs
+//   [H_RR  P_R'] [x_R]   [-H_RF x_F          ]
+//   [P_R   0   ] [mu ] = [b_P - P Uu - P_F x_F],      x = U - Uu,  x_F = (fixed value) - Uu_F,
+// and the multipliers of the fixed inputs follow from  H x + E' nu = 0.  An iteration takes whichever system is
+// smaller (|R| + |P| against |F| + |P| rows): with N inputs that is at most N / 2 + |P|.
+// The set is found by exchanging bounds (per iteration the bound whose multiplier has the
 // wrong sign by the most leaves, the bound the new point violates by the most enters) started from a prediction of
 // the set out of the previous two closed-loop steps' solves (aset_predict; the previous step's set moved one stage
 // ahead when only one is at hand); when nothing is left to exchange the KKT conditions hold, i.e. U is the unique
@@ -64,18 +72,24 @@ constexpr double ASET_MISS_TOL = 1e-12;
 // A pivot below this fraction of the row's own diagonal entry: the bound's row depends on the rows before it
 constexpr double ASET_PIV_MIN = 1e-9;
 
-// The multiplier system is solved in one of four sizes (straight-line code each, rows beyond the set are unit rows)
-template <int N> constexpr int aset_class(int i) { return 2 * N < 16 * (i + 1) ? 2 * N : 16 * (i + 1); }
-constexpr int ASET_CLASSES = 4;
+// The system is solved in one of five sizes, 8 .. 32 and 48 rows (straight-line code each, rows beyond the system are unit
+// rows).  With the smaller of the two forms per iteration a system has at most N / 2 rows plus its steering rows.
+constexpr int aset_class_rows(int i) { return i < 4 ? 8 * (i + 1) : 48; }
+template <int N> constexpr int aset_class(int i) { return 2 * N < aset_class_rows(i) ? 2 * N : aset_class_rows(i); }
+constexpr int ASET_CLASSES = 5;
+// entries of the lists the solve keeps in LDS: the rows of the largest system, or every input (the fixed inputs of the
+// free-input form)
+template <int N> constexpr int aset_list_rows() { return aset_class<N>(ASET_CLASSES - 1) > N + (N & 1) ? aset_class<N>(ASET_CLASSES - 1) : N + (N & 1); }
 // LDS the solve borrows from the wave's area (4 (N + 1) doubles: references and speeds, dead once the unconstrained
 // minimiser is formed): the list of active bounds (ints), one list of doubles and, where it fits, the 64-double slot the
 // larger classes broadcast their pivot columns through
-template <int N> constexpr int aset_list_doubles() { return aset_class<N>(ASET_CLASSES - 1) / 2 + aset_class<N>(ASET_CLASSES - 1); }
+template <int N> constexpr int aset_list_doubles() { return aset_list_rows<N>() / 2 + aset_list_rows<N>(); }
 template <int N> constexpr bool aset_lds_broadcast() { return aset_list_doubles<N>() + 64 <= 4 * (N + 1); }
 
 // LDL' of an MM x MM matrix, row r in the registers of lane r (statically indexed), the pivot column broadcast through
 // v_readlane.  A step whose pivot shows that the row depends on the rows before it is skipped: the multiplier of that
-// row comes out as zero and the lane is left with dinv = 0 as the mark.
+// row comes out as zero and the lane is left with dinv = 0 as the mark.  Pivots may be negative (a positive definite
+// block bordered by constraint rows, eliminated in that order, needs no pivoting).
 template <int MM>
 struct SmallLdl {
     double row[MM];
@@ -94,7 +108,7 @@ struct SmallLdl {
         const double c = row[K];
         if (NL) bc[lane_in] = c;
         const double piv = bcast(c, K);
-        const double inv = piv > ASET_PIV_MIN * bcast(diag, K) ? fast_rcp(piv) : 0.0;
+        const double inv = fabs(piv) > ASET_PIV_MIN * bcast(diag, K) ? fast_rcp(piv) : 0.0;   // (negative: the bordered system of the free-input form)
         const bool below = lane > K;
         const double l = below ? c * inv : 0.0;
         if (lane == K) dinv = inv;
@@ -213,6 +227,19 @@ __device__ __forceinline__ double aset_steer_multiplier(int lane, int ad, bool i
 
 enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 };
 
+// Developer builds with -DASET_TIMING: shader-clock cycles per phase of the solve, summed over the waves of a launch
+// (g_aset_t, read through mpc_debug_aset_timing; run few scenarios so that a wave has its SIMD to itself).
+#ifdef ASET_TIMING
+extern __device__ unsigned long long g_aset_t[24];
+#define AT_BEGIN() long long at0_ = clock64()
+#define AT(i) do { const long long at1_ = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_aset_t[i], (unsigned long long)(at1_ - at0_)); } at0_ = clock64(); } while (0)
+#define AT_COUNT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_aset_t[i], 1ull); } while (0)
+#else
+#define AT_BEGIN() do {} while (0)
+#define AT(i) do {} while (0)
+#define AT_COUNT(i) do {} while (0)
+#endif
+
 // History of a scenario's solves behind its warm-start record (the record itself: [5][WAVE] inputs and multipliers, a
 // validity flag and two back-off counters): two slots of [4][WAVE] doubles -- signed multipliers of the input and of
 // the steering bounds (positive at the upper bound, zero where the bound is not active), and the distance of every
@@ -268,6 +295,20 @@ struct AsetResult {
                        // settle within ASET_MAX_ITER, UNCERTIFIED the corrections of the certificate stayed too large
 };
 
+#ifndef ASET_FREE_FORM
+#define ASET_FREE_FORM 1
+#endif
+
+// Rows of the system an iteration solves for the set (au, ad): the smaller of the two forms above.
+template <int N>
+__device__ __forceinline__ int aset_system_rows(int lane, int au, int ad)
+{
+    const int ad_prev = lane > 0 ? lane_read(ad, max(lane - 1, 0)) : 0;
+    const bool in_run = ad != 0 && ad_prev == ad;
+    const int n_fix = __popcll(__ballot(au != 0 || in_run)), n_pre = __popcll(__ballot(ad != 0 && !in_run));
+    return ASET_FREE_FORM ? min(n_fix, N - n_fix) + n_pre : n_fix + n_pre;
+}
+
 // The iteration in one size class, from the set (au, ad) and iteration count `it0`.  Uu: this lane's unconstrained
 // minimiser (0 beyond the horizon), vdu = dt * prefix sum of Uu; up_d / lo_d: this lane's steering bounds
 // (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
@@ -285,9 +326,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     const bool valid = lane < N, validd = lane < N - 1;
     const unsigned lc = valid ? lane : 0;
     aset_lint *cid_l = (aset_lint *)lds;
-    aset_ldouble *val_l = (aset_ldouble *)(lds + aset_class<N>(ASET_CLASSES - 1) / 2);
+    aset_ldouble *val_l = (aset_ldouble *)(lds + aset_list_rows<N>() / 2);
     aset_ldouble *bc = (aset_ldouble *)(lds + aset_list_doubles<N>());
-    constexpr bool USE_LDS = MM >= 32 && aset_lds_broadcast<N>();
+    constexpr bool USE_LDS = MM >= 24 && aset_lds_broadcast<N>();
     const aset_gdouble *Tg = (const aset_gdouble *)T;
     const aset_gdouble *Hg = (const aset_gdouble *)Hm;
     const double tol_u = 1e-12 * umax, tol_d = 1e-12 * dmax;
@@ -297,9 +338,16 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     double U = Uu, nu_u = 0.0, nu_d = 0.0, nu = 0.0, tm = 0.0, b_run = 0.0;
     int my_cid = 0, m = 0, rank_u = 0, rank_d = 0;
     bool converged = false, in_run = false;
+    // the free-input form's state of the last iteration
+    unsigned long long mask_fix = 0ull, mask_pre = 0ull;
+    int n_free = 0, msys = 0, rank_f = 0, rank_p = 0;
+    bool free_form = false;
+    double res_free = 0.0;
     const int it_cap = MM <= 32 ? ASET_MAX_ITER : cap_large;
+    AT_BEGIN();
 #pragma unroll 1
     for (int it = it0; it < it_cap; it++) {
+        AT_COUNT(16);
         // a steering bound whose predecessor stage is active on the same side enters as "this input = the step between
         // the two bounds" (0 unless the bound was widened): see aset_steer_multiplier.  Such an input cannot sit at its
         // rate bound as well (the step between two steering bounds is never the full rate): that bound leaves the set.
@@ -315,10 +363,92 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         const unsigned long long mask_u = __ballot(au != 0), mask_d = __ballot(ad != 0);
         const int m_u = __popcll(mask_u);
         m = m_u + __popcll(mask_d);
-        if (m > MM) { out.au = au; out.ad = ad; out.iters = it; out.why = ASET_GROW; return out; }
+        const unsigned long long mask_run = __ballot(in_run);
+        mask_fix = mask_u | mask_run;                    // inputs the set fixes (an in_run lane has au = 0)
+        mask_pre = mask_d & ~mask_run;                   // steering rows that stay rows
+        n_free = N - __popcll(mask_fix);
+        free_form = ASET_FREE_FORM && n_free + __popcll(mask_pre) < m;
+        msys = free_form ? n_free + __popcll(mask_pre) : m;
+        if (msys > MM) { out.au = au; out.ad = ad; out.iters = it; out.why = ASET_GROW; return out; }
         out.iters = it + 1;
-        out.flops += m * m * m / 3 + 2 * m * m + 2 * m * N + 20 * N;
+        out.flops += msys * msys * msys / 3 + 2 * msys * msys + 2 * m * N + 20 * N;
         const unsigned long long below = (1ull << lane) - 1ull;
+        if (free_form) {
+            // ---- the free-input form
+            const bool is_fix = (mask_fix >> lane) & 1ull, is_pre = (mask_pre >> lane) & 1ull, is_free = valid && !is_fix;
+            const int rank_x = __popcll(mask_fix & below);
+            rank_f = __popcll(~mask_fix & below);                             // (lanes below a valid one are valid)
+            rank_p = n_free + __popcll(mask_pre & below);
+            const double xF = is_fix ? (au != 0 ? (au > 0 ? umax : -umax) : b_run) - Uu : 0.0;
+            // y = H[:, F] x_F for every stage: the fixed inputs and their steps in lanes 0..|F|-1
+            if (is_fix) { cid_l[rank_x] = lane; val_l[rank_x] = xF; }
+            wave_sync();
+            const int n_fix = N - n_free;
+            const int cidF = lane < n_fix ? cid_l[lane] : 0;
+            const double wF = lane < n_fix ? val_l[lane] : 0.0;
+            wave_sync();
+            const double y = valid ? aset_combine<(unsigned)N, ASET_ROWS_LARGE>(Hg, cidF, wF, n_fix, lc, 0.0, 1.0) : 0.0;
+            const double pxF = dt * incl_prefix(xF, lane);
+            // the system's rows in lanes 0..msys-1: free inputs (their stage), then steering rows (N + stage)
+            if (is_free) { cid_l[rank_f] = lane; val_l[rank_f] = -y; }
+            if (is_pre) { cid_l[rank_p] = N + lane; val_l[rank_p] = b_run - vdu - pxF; }
+            wave_sync();
+            const bool act = lane < msys;
+            my_cid = act ? cid_l[lane] : 0;
+            const double my_d = act ? val_l[lane] : 0.0;
+            wave_sync();
+            AT(0);
+            const bool row_free = my_cid < N;
+            const int my_stage = row_free ? my_cid : my_cid - N;
+            // (the steering row's own entry of the table bounds its pivot: inv(H_RR) <= inv(H)_RR)
+            const double diag0 = act ? (row_free ? Hg[(unsigned)my_cid * N + (unsigned)my_cid] : Tg[(unsigned)my_cid * LD + (unsigned)my_cid]) : 1.0;
+            const int lane_o = opaque_int(lane);
+#pragma unroll
+            for (int s0 = 0; s0 < MM; s0 += ASET_GATHER_CHUNK) {
+                double t[ASET_GATHER_CHUNK];
+#pragma unroll
+                for (int g = 0; g < ASET_GATHER_CHUNK; g++) {
+                    if (s0 + g < MM) {
+                        const int cs = __builtin_amdgcn_readlane(my_cid, s0 + g);
+                        t[g] = (Hg + (cs < N ? cs : 0) * N)[row_free ? my_stage : 0];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < ASET_GATHER_CHUNK; g++) {
+                    if (s0 + g < MM) {
+                        const int cs = __builtin_amdgcn_readlane(my_cid, s0 + g);
+                        const bool col_free = cs < N;
+                        const int cstage = col_free ? cs : cs - N;
+                        const double border = (row_free != col_free && (row_free ? my_stage <= cstage : cstage <= my_stage)) ? dt : 0.0;
+                        const double v = (row_free && col_free) ? t[g] : border;
+                        ldl.row[s0 + g] = (act && s0 + g < msys) ? v : (lane_o == s0 + g ? 1.0 : 0.0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            AT(1);
+            ldl.template factor<USE_LDS>(lane, diag0, bc);
+            AT(2);
+            const double sol = ldl.solve(my_d, lane);
+            // (a steering row no free input stands before -- the fixed ones decide that angle -- was left out: it leaves)
+            if (act) val_l[lane] = ldl.dinv == 0.0 ? __builtin_nan("") : sol;
+            wave_sync();
+            const double xR = is_free ? val_l[rank_f] : 0.0;
+            const double muP = is_pre ? val_l[rank_p] : 0.0;
+            wave_sync();
+            U = valid ? Uu + (is_fix ? xF : xR) : 0.0;
+            AT(3);
+            // H x for every stage, and with it the multipliers of the fixed inputs:  nu_F = -(H x + P' mu)_F
+            const double solc = (act && row_free && ldl.dinv != 0.0) ? sol : 0.0;
+            const double hx = valid ? aset_combine<(unsigned)N, ASET_ROWS_LARGE>(Hg, my_cid, solc, n_free, lc, y, 1.0) : 0.0;
+            const double force = hx + dt * incl_suffix((is_pre && muP == muP) ? muP : 0.0, lane);
+            res_free = is_free ? force : 0.0;
+            nu_u = au != 0 ? -force : 0.0;
+            tm = ad != 0 ? (in_run ? -force : muP) : 0.0;
+            nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
+            AT(4);
+        } else {
         rank_u = __popcll(mask_u & below);
         rank_d = m_u + __popcll(mask_d & below);
         // the active bounds in lanes 0..m-1: which bound, and by how much the unconstrained minimiser misses it
@@ -329,6 +459,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         my_cid = act ? cid_l[lane] : 0;
         const double my_d = act ? val_l[lane] : 0.0;
         wave_sync();
+        AT(0);
         // row `lane` of E inv(H) E', gathered from the table; lanes and columns beyond the set form a unit matrix
         const unsigned rowoff = (unsigned)my_cid * LD;
         const double diag0 = act ? Tg[rowoff + (unsigned)my_cid] : 1.0;
@@ -351,7 +482,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
                 if (s0 + g < MM) ldl.row[s0 + g] = (act && s0 + g < m) ? t[g] : (lane_o == s0 + g ? 1.0 : 0.0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        AT(1);
         ldl.template factor<USE_LDS>(lane, diag0, bc);
+        AT(2);
         nu = ldl.solve(my_d, lane);
         // a bound whose row depends on the rows before it (an input run that already fixes a steering row, ...) was left
         // out of the system: it leaves the set here (not-a-number fails the sign test below) and comes back if violated
@@ -361,8 +494,11 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         tm = ad != 0 ? val_l[rank_d] : 0.0;
         wave_sync();
         nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
+        AT(3);
         // U = Uu - sum_s nu_s * (column of inv(H) [I P'] of bound s)
         U = valid ? aset_combine<LD, (MM <= 16 ? ASET_ROWS_SMALL : ASET_ROWS_LARGE)>(Tg, my_cid, nu, m, lc, Uu, -1.0) : 0.0;
+        AT(4);
+        }
         const double vd = dt * incl_prefix(U, lane);
         // next set: the one bound whose multiplier has the wrong sign by the most (or whose row was left out) goes, the
         // one bound the new point violates by the most comes in.  (Exchanging every such bound at once is quicker when
@@ -374,7 +510,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         const double vi_u = (au == 0 && valid) ? (fabs(U) - umax - tol_u) / umax : -1.0;
         const double vi_d = (ad == 0 && validd) ? (fmax(vd - up_d, lo_d - vd) - tol_d) / dmax : -1.0;
         const double most = wave_max(fmax(vi_u, vi_d));
-        if (!(worst >= 0.0) && !(most > 0.0)) { converged = true; break; }
+        if (!(worst >= 0.0) && !(most > 0.0)) { converged = true; AT(5); break; }
         if (worst >= 0.0) {
             const unsigned long long cu = __ballot(sc_u == worst), cd = __ballot(sc_d == worst);
             if (cu) { if (lane == __ffsll((long long)cu) - 1) au = 0; }
@@ -385,6 +521,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             if (cu) { if (lane == __ffsll((long long)cu) - 1) au = U > 0.0 ? 1 : -1; }
             else if (lane == __ffsll((long long)cd) - 1) ad = vd > up_d ? 1 : -1;
         }
+        AT(5);
     }
     out.au = au; out.ad = ad;
     if (!converged) return out;
@@ -400,8 +537,31 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
     // (two more passes over N x N matrices per solve, about a fifth of the solve's time, for an answer that differs
     // from the 80-bit checker's by the same 1e-10 of the input bound either way).
     bool certified = false;
+    if (free_form) {
+        // The free-input form: the residual of the free rows (at hand from the multipliers' H x) and what the point
+        // misses its steering rows by go through the factorisation once more; the fixed inputs are exact by construction.
+        const bool is_fix = (mask_fix >> lane) & 1ull, is_pre = (mask_pre >> lane) & 1ull, is_free = valid && !is_fix;
+        const double vdc = dt * incl_prefix(valid ? U : 0.0, lane);
+        if (is_free) val_l[rank_f] = -res_free;
+        if (is_pre) val_l[rank_p] = b_run - vdc;
+        wave_sync();
+        const double rz = lane < msys ? val_l[lane] : 0.0;
+        wave_sync();
+        const double dsol = ldl.solve(rz, lane);
+        if (lane < msys) val_l[lane] = dsol;
+        wave_sync();
+        const double dx = is_free ? val_l[rank_f] : 0.0;
+        const double dmu = is_pre ? val_l[rank_p] : 0.0;
+        wave_sync();
+        U += dx;
+        tm += dmu;
+        nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
+        out.flops += 2 * msys * msys;
+        certified = wave_max(fabs(dx)) <= ASET_DU_EARLY * umax;
+        AT_COUNT(17);
+    }
 #pragma unroll 1
-    for (int pass = 0; pass < 3 && !certified; pass++) {
+    for (int pass = 0; pass < 3 && !certified && !free_form; pass++) {
         double z = 0.0;
         if (ASET_CERT_FROM_H) {
         const double dU = valid ? U - Uu : 0.0;
@@ -466,7 +626,9 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         U += corr;
         const double cmax = wave_max(fabs(corr));
         certified = cmax <= (pass == 0 ? ASET_DU_EARLY : ASET_DU_TOL) * umax;
+        AT_COUNT(17);
     }
+    AT(6);
     if (!certified) return out;
     // the refined point against the bounds and the signs once more, at the accuracy of the certificate
     {
@@ -496,6 +658,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         hs[3 * WAVE + lane] = fmin(up_d - vdf, vdf - lo_d) / dmax;
         if (lane == 0) w[ASET_HIST_WORD] = (double)hist;
     }
+    AT(7);
     out.U = U; out.why = ASET_SOLVED;
     return out;
 }
@@ -528,6 +691,11 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_full(MPC_ASET_ARGS)
 {
     return aset_body<N, MM>(MPC_ASET_PASS);
 }
+template <int N, int MM, int TAG>
+static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_huge(MPC_ASET_ARGS)
+{
+    return aset_body<N, MM>(MPC_ASET_PASS);
+}
 #undef MPC_ASET_ARGS
 #undef MPC_ASET_PASS
 
@@ -540,9 +708,10 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
                                                        double *rec, bool rec_valid, double *lds, int cap_large, int hist_in)
 {
-    constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3);
+    constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3), C4 = aset_class<N>(4);
     const bool valid = lane < N, validd = lane < N - 1;
     int au = 0, ad = 0;
+    AT_BEGIN();
     // the history after this solve: one step more when the previous step was solved here too, else this step alone
     const bool chain = rec_valid && (hist_in & 3) != 0;
     const int cur = (hist_in >> 2) & 1;
@@ -566,21 +735,26 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     if (!valid) au = 0;
     if (!validd) ad = 0;
     wave_sync();                                         // the borrowed LDS area is still being read as something else
+    AT(8);
     AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
-    int m = __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0));
-    if (!rec_valid && m > ASET_COLD_MAX) return r;       // a large violated set says little about the active one
+    if (!rec_valid && __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0)) > ASET_COLD_MAX) return r;   // a large violated set says little about the active one
+    int m = aset_system_rows<N>(lane, au, ad);
     if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     if (C1 > C0 && r.why == ASET_GROW) {
-        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        m = aset_system_rows<N>(lane, r.au, r.ad);
         if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
-        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        m = aset_system_rows<N>(lane, r.au, r.ad);
         if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C3 > C2 && r.why == ASET_GROW) {
-        m = __popcll(__ballot(r.au != 0)) + __popcll(__ballot(r.ad != 0));
+        m = aset_system_rows<N>(lane, r.au, r.ad);
         if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+    }
+    if (C4 > C3 && r.why == ASET_GROW) {
+        m = aset_system_rows<N>(lane, r.au, r.ad);
+        if (m <= C4) r = aset_run_huge<N, C4, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     return r;
 }

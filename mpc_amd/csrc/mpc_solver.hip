@@ -132,6 +132,15 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 #ifndef MPC_CONSTRAINED_LINKAGE
 #define MPC_CONSTRAINED_LINKAGE __noinline__ __attribute__((cold)) MPC_NOTAIL
 #endif
+#ifdef ASET_TIMING
+__device__ unsigned long long g_aset_t[24];
+extern "C" int mpc_debug_aset_timing(unsigned long long *out24, int reset)
+{
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_aset_t), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_aset_t), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 struct ConstrainedResult {
     double U, mu, res;
     int iters, status;           // interior-point iterations and status
@@ -145,6 +154,8 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
                                                                    int *as_o, int as_cap_large)
 {
     ConstrainedResult out = {0.0, 0.0, 0.0, 0, 0, 0, false};
+    AT_BEGIN();
+    AT_COUNT(18);
     // Back-off: a scenario whose active-set solves keep being handed on (the output-feedback loop on its way to the step:
     // as many active bounds as inputs) tries the method again only after 1, 3, 7, 15 steps of interior point alone.  The
     // two counters (steps to wait, failures in a row) travel in the scenario's record behind its validity flag.
@@ -156,12 +167,14 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
     const int hist_raw = __builtin_amdgcn_readfirstlane((int)bo2);
     const int hist = as_cap_large == ASET_CAP_LARGE_NOISY ? ((hist_raw & ~3) | min(hist_raw & 3, 1)) : hist_raw;
     const int wait = __builtin_amdgcn_readfirstlane((int)bo0);                  // wave-uniform
+    AT(9);
     if (T && wait > 0) {
         if (lane == 0) bo[0] = (double)(wait - 1);
     } else if (T) {
         const AsetResult r = active_set_solve<N, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
                                                       prm.warm_mode != 0, lds, as_cap_large, hist);
         out.work = r.iters;
+        AT(10);
         // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
         // registers of the step loop they would crowd the unconstrained steps.  (Atomics without a return value: nothing
         // waits for them.)
@@ -178,6 +191,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
         }
         if (r.why == ASET_SOLVED) {
             out.U = r.U; out.warm_valid = prm.warm != nullptr;
+            AT(11);
             return out;
         }
     }
@@ -350,6 +364,9 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
 
 #pragma unroll 1
     for (int t = 0; t < nsteps; t++) {
+#ifdef ASET_TIMING
+        const long long step_t0 = clock64();
+#endif
         // ------------------------------------------------------------ 1. initial state and references
         double xh3, xh4, xh5;               // controller start [0,0,0,vy,r,delta] (LMPC2.py:298)
         double dhat = 0.0;
@@ -710,6 +727,12 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
             }
         }
         wave_sync();
+#ifdef ASET_TIMING
+        if (lane == 0) {
+            atomicAdd(&g_aset_t[constrained ? 12 : 13], (unsigned long long)(clock64() - step_t0));
+            atomicAdd(&g_aset_t[constrained ? 19 : 20], 1ull);
+        }
+#endif
     }   // steps of this launch
 
     if (a.mode != MODE_SOLVE) {
