@@ -334,6 +334,7 @@ static void attach_cache(const mpc_handle *h, mpc::SolveArgs &a)
         a.sh_T = h->sh_T_ok ? h->sh_T : nullptr;
     }
     a.as_out = h->as2;
+    a.general_aset = h->cfg.qp_method != MPC_QP_INTERIOR_POINT ? 1 : 0;
 }
 
 static hipError_t launch_for_kind(const mpc_handle *h, mpc::SolveArgs &a, hipStream_t st)

@@ -38,7 +38,10 @@ typedef __attribute__((address_space(3))) int aset_lint;
 
 // iteration caps (counted over the whole solve): an iteration of the largest size class costs about as much as one of
 // the interior point, so a set of that size that has not settled after a few exchanges is handed on
-constexpr int ASET_MAX_ITER = 10;       // size classes up to 32
+#ifndef ASET_MAX_ITER_N
+#define ASET_MAX_ITER_N 10
+#endif
+constexpr int ASET_MAX_ITER = ASET_MAX_ITER_N;       // size classes up to 32
 constexpr int ASET_CAP_LARGE = 6;       // the larger classes; the caller passes its own (`cap_large`): the output-feedback
 constexpr int ASET_CAP_LARGE_NOISY = 4; // loop, whose sets jump with the estimate's noise, hands on earlier (measured)
 constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a previous set starts from
@@ -230,7 +233,7 @@ enum { ASET_SOLVED = 0, ASET_GROW = 1, ASET_UNSETTLED = 3, ASET_UNCERTIFIED = 4 
 // Developer builds with -DASET_TIMING: shader-clock cycles per phase of the solve, summed over the waves of a launch
 // (g_aset_t, read through mpc_debug_aset_timing; run few scenarios so that a wave has its SIMD to itself).
 #ifdef ASET_TIMING
-extern __device__ unsigned long long g_aset_t[24];
+static __device__ unsigned long long g_aset_t[24];      // (one per translation unit; the reader sits in mpc_solver.hip)
 #define AT_BEGIN() long long at0_ = clock64()
 #define AT(i) do { const long long at1_ = clock64(); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_aset_t[i], (unsigned long long)(at1_ - at0_)); } at0_ = clock64(); } while (0)
 #define AT_COUNT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_aset_t[i], 1ull); } while (0)
@@ -299,25 +302,27 @@ struct AsetResult {
 #define ASET_FREE_FORM 1
 #endif
 
-// Rows of the system an iteration solves for the set (au, ad): the smaller of the two forms above.
-template <int N>
+// Rows of the system an iteration solves for the set (au, ad): the smaller of the two forms above; without the table
+// (DUAL = false: kernels whose H differs per scenario and solve) the free-input form, which needs H alone.
+template <int N, bool DUAL>
 __device__ __forceinline__ int aset_system_rows(int lane, int au, int ad)
 {
     const int ad_prev = lane > 0 ? lane_read(ad, max(lane - 1, 0)) : 0;
     const bool in_run = ad != 0 && ad_prev == ad;
     const int n_fix = __popcll(__ballot(au != 0 || in_run)), n_pre = __popcll(__ballot(ad != 0 && !in_run));
+    if (!DUAL) return N - n_fix + n_pre;
     return ASET_FREE_FORM ? min(n_fix, N - n_fix) + n_pre : n_fix + n_pre;
 }
 
 // The iteration in one size class, from the set (au, ad) and iteration count `it0`.  Uu: this lane's unconstrained
 // minimiser (0 beyond the horizon), vdu = dt * prefix sum of Uu; up_d / lo_d: this lane's steering bounds
-// (steer_bounds()); T: the table above, row length 2N; Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
+// (steer_bounds()); T: the table above, row length 2N (not read when DUAL is false); Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
 // ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
 // written with the result when the solve succeeds, together with the history slot and word `hist` names (or NULL); lds:
 // the wave's 4 (N + 1) doubles of references and speeds.
 // Inlined into the caller's one non-inlined function of the constrained step (solve_constrained in mpc_solver.hip), whose
 // registers stay out of the per-step path's allocation.
-template <int N, int MM>
+template <int N, int MM, bool DUAL = true>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
                                                 double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist)
@@ -367,7 +372,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         mask_fix = mask_u | mask_run;                    // inputs the set fixes (an in_run lane has au = 0)
         mask_pre = mask_d & ~mask_run;                   // steering rows that stay rows
         n_free = N - __popcll(mask_fix);
-        free_form = ASET_FREE_FORM && n_free + __popcll(mask_pre) < m;
+        free_form = !DUAL || (ASET_FREE_FORM && n_free + __popcll(mask_pre) < m);
         msys = free_form ? n_free + __popcll(mask_pre) : m;
         if (msys > MM) { out.au = au; out.ad = ad; out.iters = it; out.why = ASET_GROW; return out; }
         out.iters = it + 1;
@@ -400,8 +405,12 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             AT(0);
             const bool row_free = my_cid < N;
             const int my_stage = row_free ? my_cid : my_cid - N;
-            // (the steering row's own entry of the table bounds its pivot: inv(H_RR) <= inv(H)_RR)
-            const double diag0 = act ? (row_free ? Hg[(unsigned)my_cid * N + (unsigned)my_cid] : Tg[(unsigned)my_cid * LD + (unsigned)my_cid]) : 1.0;
+            // (the steering row's own entry of the table bounds its pivot: inv(H_RR) <= inv(H)_RR; without the table, the
+            // share of one free input of that stage's size)
+            const double hdiag = Hg[(unsigned)my_stage * N + (unsigned)my_stage];
+            double diag0 = 1.0;
+            if (DUAL) { if (act) diag0 = row_free ? hdiag : Tg[(unsigned)my_cid * LD + (unsigned)my_cid]; }
+            else if (act) diag0 = row_free ? hdiag : dt * dt / hdiag;
             const int lane_o = opaque_int(lane);
 #pragma unroll
             for (int s0 = 0; s0 < MM; s0 += ASET_GATHER_CHUNK) {
@@ -448,7 +457,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             tm = ad != 0 ? (in_run ? -force : muP) : 0.0;
             nu_d = aset_steer_multiplier(lane, ad, in_run, tm, dt);
             AT(4);
-        } else {
+        } else if (DUAL) {
         rank_u = __popcll(mask_u & below);
         rank_d = m_u + __popcll(mask_d & below);
         // the active bounds in lanes 0..m-1: which bound, and by how much the unconstrained minimiser misses it
@@ -561,7 +570,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         AT_COUNT(17);
     }
 #pragma unroll 1
-    for (int pass = 0; pass < 3 && !certified && !free_form; pass++) {
+    for (int pass = 0; DUAL && pass < 3 && !certified && !free_form; pass++) {
         double z = 0.0;
         if (ASET_CERT_FROM_H) {
         const double dU = valid ? U - Uu : 0.0;
@@ -671,49 +680,50 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
                       double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist
 #define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large, hist
-template <int N, int MM, int TAG>
+template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_small(MPC_ASET_ARGS)
 {
-    return aset_body<N, MM>(MPC_ASET_PASS);
+    return aset_body<N, MM, DUAL>(MPC_ASET_PASS);
 }
-template <int N, int MM, int TAG>
+template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_medium(MPC_ASET_ARGS)
 {
-    return aset_body<N, MM>(MPC_ASET_PASS);
+    return aset_body<N, MM, DUAL>(MPC_ASET_PASS);
 }
-template <int N, int MM, int TAG>
+template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_large(MPC_ASET_ARGS)
 {
-    return aset_body<N, MM>(MPC_ASET_PASS);
+    return aset_body<N, MM, DUAL>(MPC_ASET_PASS);
 }
-template <int N, int MM, int TAG>
+template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_full(MPC_ASET_ARGS)
 {
-    return aset_body<N, MM>(MPC_ASET_PASS);
+    return aset_body<N, MM, DUAL>(MPC_ASET_PASS);
 }
-template <int N, int MM, int TAG>
+template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_huge(MPC_ASET_ARGS)
 {
-    return aset_body<N, MM>(MPC_ASET_PASS);
+    return aset_body<N, MM, DUAL>(MPC_ASET_PASS);
 }
 #undef MPC_ASET_ARGS
 #undef MPC_ASET_PASS
 
-// One solve: the starting set (aset_predict when rec_valid and the record's history `hist_in` holds two steps, the
-// previous step's set one stage ahead when rec_valid, else what the unconstrained minimiser violates), then the
-// iteration in the smallest size class that holds the set, moving up a class when the set outgrows it.  Arguments as
-// aset_body.
-template <int N, int TAG>
+// One solve: the starting set, then the iteration in the smallest size class that holds the set, moving up a class when
+// the set outgrows it.  warm_mode 0: start from what the unconstrained minimiser violates; 1: from the set in the record
+// (the previous solve of the same closed-loop step); 2: the record is the previous closed-loop step's -- aset_predict
+// when its history `hist_in` holds two steps, else its set one stage ahead.  Other arguments as aset_body.
+template <int N, int TAG, bool DUAL = true>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
-                                                       double *rec, bool rec_valid, double *lds, int cap_large, int hist_in)
+                                                       double *rec, int warm_mode, double *lds, int cap_large, int hist_in)
 {
+    const bool rec_valid = warm_mode != 0;
     constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3), C4 = aset_class<N>(4);
     const bool valid = lane < N, validd = lane < N - 1;
     int au = 0, ad = 0;
     AT_BEGIN();
     // the history after this solve: one step more when the previous step was solved here too, else this step alone
-    const bool chain = rec_valid && (hist_in & 3) != 0;
+    const bool chain = warm_mode == 2 && (hist_in & 3) != 0;
     const int cur = (hist_in >> 2) & 1;
     const int hist = chain ? (min((hist_in & 3) + 1, 2) | ((cur ^ 1) << 2)) : 1;
     if (chain && (hist_in & 3) == 2) {
@@ -724,7 +734,8 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     } else if (rec_valid) {
         const aset_gdouble *w = (const aset_gdouble *)rec;
         const int lc = valid ? lane : 0;
-        const int ln = min(lc + 1, N - 1), lnd = min(lc + 1, N - 2);
+        const int sh = warm_mode == 2 ? 1 : 0;
+        const int ln = min(lc + sh, N - 1), lnd = min(lc + sh, N - 2);
         const double a0 = w[WAVE + ln], a1 = w[2 * WAVE + ln], a2 = w[3 * WAVE + lnd], a3 = w[4 * WAVE + lnd];
         au = a0 > 0.0 ? 1 : (a1 > 0.0 ? -1 : 0);
         ad = a2 > 0.0 ? 1 : (a3 > 0.0 ? -1 : 0);
@@ -738,23 +749,23 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     AT(8);
     AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
     if (!rec_valid && __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0)) > ASET_COLD_MAX) return r;   // a large violated set says little about the active one
-    int m = aset_system_rows<N>(lane, au, ad);
-    if (m <= C0) r = aset_run_small<N, C0, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+    int m = aset_system_rows<N, DUAL>(lane, au, ad);
+    if (m <= C0) r = aset_run_small<N, C0, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     if (C1 > C0 && r.why == ASET_GROW) {
-        m = aset_system_rows<N>(lane, r.au, r.ad);
-        if (m <= C1) r = aset_run_medium<N, C1, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
+        if (m <= C1) r = aset_run_medium<N, C1, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
-        m = aset_system_rows<N>(lane, r.au, r.ad);
-        if (m <= C2) r = aset_run_large<N, C2, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
+        if (m <= C2) r = aset_run_large<N, C2, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C3 > C2 && r.why == ASET_GROW) {
-        m = aset_system_rows<N>(lane, r.au, r.ad);
-        if (m <= C3) r = aset_run_full<N, C3, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
+        if (m <= C3) r = aset_run_full<N, C3, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     if (C4 > C3 && r.why == ASET_GROW) {
-        m = aset_system_rows<N>(lane, r.au, r.ad);
-        if (m <= C4) r = aset_run_huge<N, C4, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
+        if (m <= C4) r = aset_run_huge<N, C4, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
     }
     return r;
 }

@@ -352,13 +352,11 @@ static __device__ __noinline__ MPC_NOTAIL IpmResult interior_point(IpmParams prm
     }
     if (prm.warm && rec_ok) {
         gdouble *w = (gdouble *)prm.warm;
-        if (TAG != 3) {
-            // the multiplier of a bound that is not active (slack above multiplier at the end of the path) goes into the
-            // record as an exact zero: the next warm start lifts it to its floor either way, and the active-set solve of
-            // the fixed-model kernels reads the record as "active where positive"
-            lpu = lpu > tpu ? lpu : 0.0; lmu = lmu > tmu ? lmu : 0.0;
-            lpd = lpd > tpd ? lpd : 0.0; lmd = lmd > tmd ? lmd : 0.0;
-        }
+        // the multiplier of a bound that is not active (slack above multiplier at the end of the path) goes into the
+        // record as an exact zero: the next warm start lifts it to its floor either way, and the active-set solves read
+        // the record as "active where positive"
+        lpu = lpu > tpu ? lpu : 0.0; lmu = lmu > tmu ? lmu : 0.0;
+        lpd = lpd > tpd ? lpd : 0.0; lmd = lmd > tmd ? lmd : 0.0;
         if (valid) { w[lane] = U; w[WAVE + lane] = lpu; w[2 * WAVE + lane] = lmu; w[3 * WAVE + lane] = lpd; w[4 * WAVE + lane] = lmd; }
     }
     IpmResult out = {U, mu, res, iters, status, rec_ok && status == 0};

@@ -85,6 +85,9 @@ struct SolveArgs {
     // mpc_config.emulate_acados: the SQP iterate (predicted states of the previous solve) per scenario, [B][6][N+1], read as
     // the anchor of the regularisation and updated; NULL = off
     double *sqp_x;
+    // Kernels whose Hessian differs per scenario and solve (NL): 1 = try the active-set solve in its free-input form (it
+    // needs H alone) before the interior point; as_out receives its counters as on the fixed-model path
+    int general_aset;
 };
 
 // Raises a kernel's dynamic-LDS limit to the CU's 160 KB once per device and kernel (`done` is that kernel's flag table).

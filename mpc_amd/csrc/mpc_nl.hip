@@ -11,14 +11,65 @@
 //   5. the full step is taken; the iteration stops when the step falls below the tolerance.
 // The input iterate is kept between calls, as the reference's solver object keeps its iterate (NLMPC.py:232).
 #include "mpc_ipm.hpp"
+#include "mpc_aset.hpp"
 
 #pragma clang fp contract(fast)
 
 namespace mpc {
 
+
 constexpr int NL_STAGE_W = 42;   // A[7][5] (columns cos, sin, vy, r, delta; the px and py columns are unit vectors) + b[7]
 
 struct NlCoef { double vx, a11, a12, a21, a22, b1, b2; };
+
+// A QP of the SQP iteration whose unconstrained minimiser Uu violates a bound: the active-set solve in its free-input
+// form (H of this scenario and iteration is all it needs), started from the previous QP's set -- the previous closed-loop
+// step's moved one stage ahead (prm.warm_mode 2) or the previous SQP iteration's as it is (1) -- and the interior point
+// for what it hands on, with the back-off of the fixed-model kernels' constrained step (1, 3, 7, 15 QPs of interior
+// point alone after solves that were handed on).  One call site in the SQP loop, a function of its own.
+struct NlQpResult {
+    double U, mu, res;
+    int iters, status;           // interior-point iterations and status
+    bool warm_valid;
+};
+
+template <int N>
+static __device__ __noinline__ __attribute__((cold)) MPC_NOTAIL NlQpResult nl_solve_constrained(IpmParams prm, int lane, const double *Hm, double g,
+                                                                                   double Uu, double vdu, double up_d, double lo_d,
+                                                                                   double *lds, int *as_o, bool try_aset)
+{
+    NlQpResult out = {0.0, 0.0, 0.0, 0, 0, false};
+    gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
+    if (try_aset && bo) {
+        const double bo0 = bo[0], bo1 = bo[1];
+        const int wait = __builtin_amdgcn_readfirstlane((int)bo0);
+        if (wait > 0) {
+            if (lane == 0) bo[0] = (double)(wait - 1);
+        } else {
+            // (history word 1: the record is read as the previous solve's set, never extrapolated -- the QPs of one step's
+            // SQP iterations are not consecutive steps)
+            const AsetResult r = active_set_solve<N, 3, false>(lane, nullptr, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
+                                                               prm.warm_mode, lds, ASET_CAP_LARGE, 1);
+            if (as_o && lane == 0) {
+                atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
+                atomicAdd(&as_o[1], r.iters);
+                atomicAdd(&as_o[4], (r.flops + 32) >> 6);
+            }
+            if (lane == 0) {
+                const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
+                if ((double)streak != bo1) bo[1] = (double)streak;
+                if (streak) bo[0] = (double)((1 << streak) - 1);
+            }
+            if (r.why == ASET_SOLVED) {
+                out.U = r.U; out.warm_valid = true;
+                return out;
+            }
+        }
+    }
+    const IpmResult r = interior_point<N, 3>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)lds);
+    out.U = r.U; out.mu = r.mu; out.res = r.res; out.iters = r.iters; out.status = r.status; out.warm_valid = r.warm_valid;
+    return out;
+}
 
 // NLMPC.py:108-134
 __device__ __forceinline__ void nl_f(const double *x, double u, const NlCoef &c, double *xd)
@@ -163,6 +214,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
     int iters_tot = 0, status_max = 0, nconstr = 0, sqp_tot = 0, lap_flag = 0;
     double mu = 0.0, res = 0.0, u0 = 0.0;
     double *Hw = a.Hws + (size_t)s * N * N;
+    if (lane == 0 && a.as_out && !a.accumulate) { int *o = a.as_out + 6 * (size_t)s; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; }
     // closed-loop statistics of the scenario (lane i carries statistic i).  The stage cost is the NL controller's:
     // y = [px, py, cos, sin, vy, r, delta | u] against [x, y, cos, sin, 0, 0, 0 | 0] (NLMPC.py:159-186, 208-212).
     const bool cl_on = a.stat_out != nullptr && a.mode != MODE_SOLVE;
@@ -368,7 +420,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 // closed-loop step's moved one stage ahead
                 const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
                 const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm, Ne};
-                const IpmResult r = interior_point<N, 3>(prm, lane, Hw, gq, up_d, lo_d, (ldouble *)s_wv);
+                const NlQpResult r = nl_solve_constrained<N>(prm, lane, Hw, gq, Un, vd, up_d, lo_d, s_wv,
+                                                             a.as_out ? a.as_out + 6 * (size_t)s : nullptr, a.general_aset != 0 && Ne == N);
                 Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
                 if (r.status) status_max = max(status_max, r.status);
                 warm_ok = (warm_rec != nullptr) && r.warm_valid;

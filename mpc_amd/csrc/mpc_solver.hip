@@ -133,7 +133,6 @@ __device__ __forceinline__ void condense(const DevCfg &cfg, int lane, const doub
 #define MPC_CONSTRAINED_LINKAGE __noinline__ __attribute__((cold)) MPC_NOTAIL
 #endif
 #ifdef ASET_TIMING
-__device__ unsigned long long g_aset_t[24];
 extern "C" int mpc_debug_aset_timing(unsigned long long *out24, int reset)
 {
     if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_aset_t), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
@@ -172,7 +171,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
         if (lane == 0) bo[0] = (double)(wait - 1);
     } else if (T) {
         const AsetResult r = active_set_solve<N, TAG>(lane, T, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
-                                                      prm.warm_mode != 0, lds, as_cap_large, hist);
+                                                      prm.warm_mode, lds, as_cap_large, hist);
         out.work = r.iters;
         AT(10);
         // the scenario's active-set counters live in memory (SolveArgs::as_out): they change on these steps only, and as
