@@ -50,7 +50,8 @@ def ipm_flops(N: int) -> float:
     return N ** 3 / 3 + 9 * N * N + 100 * N
 
 
-def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0, ncomp: int = 3, extra: float = 0.0) -> float:
+def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float = 0.0, ncomp: int = 3, extra: float = 0.0,
+                      aset_qps: float = 0.0) -> float:
     """FP64 flops one scenario-step needs with the method that is run (symmetry and zero weights exploited).
     c2/c4 (speed constant, problem condensed once per launch and shared): planner 60(N+1); unconstrained minimiser as
     an affine map of the step's data, `ncomp` weighted reference components (2 with the yaml's weights: the x weight is
@@ -61,17 +62,19 @@ def algorithmic_flops(workload: str, N: int, mean_iters: float, mean_sqp: float 
     300 on average); per interior-point iteration ~880 (step and roll-out 75, Riccati matrix and vector recursion with
     the barrier terms 400, affine forward sweep 120, corrector backward sweep 150, corrector forward sweep 130).
     c5, per SQP iteration: RK4 roll-out 160N; RK4 derivative 700N; prediction columns 52N^2/2; Hessian, 5 weighted
-    outputs, 5N^3/3; gradient and H*U 4N^2; LDL' N^3/3 + 2N^2.
-    Every interior-point iteration of c2/c4/c5 adds ipm_flops(N); the active-set solves of c2/c4 add the count the kernel
-    keeps for them (`extra`, per scenario-step: LDL' of the m x m multiplier system m^3/3, two solves 2m^2, the update of
-    the inputs 2mN, scans ~20N per iteration; 2m^2 + 2mN per refinement pass)."""
+    outputs, 5N^3/3; gradient and H*U 4N^2; LDL' N^3/3 + 2N^2 for the unconstrained minimiser -- not counted for the
+    `aset_qps` QPs per scenario-step that the active-set solve finishes (it is tried before that factorisation whenever
+    the previous QP was constrained; the few it finishes after a cold start are left out as well, which undercounts).
+    Every interior-point iteration of c2/c4/c5 adds ipm_flops(N); the active-set solves add the count the kernel keeps
+    for them (`extra`, per scenario-step: LDL' of the m x m system m^3/3, two solves 2m^2, the update of the inputs 2mN,
+    scans ~20N per iteration; 2m^2 + 2mN per refinement pass)."""
     plan = 60 * (N + 1) + 400
     if workload in ("c2", "c4"):
         fixed = plan + 2 * (ncomp * N * N + 5 * N) + 10 * N + (8000 if workload == "c4" else 0)
     elif workload == "c3":
         return plan + N * (130 + 300 + 880 * mean_iters)
     else:
-        fixed = plan + mean_sqp * (860 * N + 26 * N * N + 5 * N ** 3 / 3 + 4 * N * N + N ** 3 / 3 + 2 * N * N)
+        fixed = plan + mean_sqp * (860 * N + 26 * N * N + 5 * N ** 3 / 3 + 4 * N * N) + max(0.0, mean_sqp - aset_qps) * (N ** 3 / 3 + 2 * N * N)
     return fixed + ipm_flops(N) * mean_iters + extra
 
 
@@ -432,7 +435,8 @@ def main() -> None:
         mean_sqp = sums["sqp_iterations"] / total
         ncomp = weighted_reference_components(sim.ocp) if args.workload in ("c2", "c4") else 3
         as_scale = 1.0 if not args.per_step_launch else float(args.steps)      # per-step launches: the last step stands for all
-        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp, ncomp, extra=as_scale * sums["active_set_flops"] / total)
+        flops = algorithmic_flops(args.workload, N, mean_iters, mean_sqp, ncomp, extra=as_scale * sums["active_set_flops"] / total,
+                                  aset_qps=as_scale * sums["active_set_solves"] / total if args.workload == "c5" else 0.0)
         launch_s = float(kernel_ms.mean()) * 1e-3
         ach_tflops = flops * B * steps_per_launch / launch_s / 1e12
         out = {
@@ -455,7 +459,7 @@ def main() -> None:
             "solver": {"mean_ipm_iterations_per_scenario_step": mean_iters,
                        "constrained_qp_per_scenario_step": sums["constrained_solves"] / total,
                        "mean_sqp_iterations_per_scenario_step": mean_sqp if args.workload == "c5" else None,
-                       "active_set": None if args.workload not in ("c2", "c4") else {
+                       "active_set": None if args.workload not in ("c2", "c4", "c5") else {
                            "solves_per_scenario_step": as_scale * sums["active_set_solves"] / total,
                            "iterations_per_solve": sums["active_set_iterations"] / max(1.0, sums["active_set_solves"] + sums["active_set_handed_on"]),
                            "handed_to_interior_point_per_scenario_step": as_scale * sums["active_set_handed_on"] / total,

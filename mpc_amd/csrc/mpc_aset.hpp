@@ -319,13 +319,16 @@ __device__ __forceinline__ int aset_system_rows(int lane, int au, int ad)
 // (steer_bounds()); T: the table above, row length 2N (not read when DUAL is false); Hm: H, [N][N] symmetric; rec: the scenario's warm-start record
 // ([5][WAVE]: inputs, then the multipliers of the upper / lower input bounds and upper / lower steering bounds),
 // written with the result when the solve succeeds, together with the history slot and word `hist` names (or NULL); lds:
-// the wave's 4 (N + 1) doubles of references and speeds.
+// the wave's 4 (N + 1) doubles of references and speeds.  g0: this lane's entry of the objective's gradient at Uu -- zero
+// when Uu is the unconstrained minimiser; the free-input form works about any point (DUAL = false: e.g. the current
+// iterate of an SQP method, which saves the factorisation of H that the unconstrained minimiser costs).
 // Inlined into the caller's one non-inlined function of the constrained step (solve_constrained in mpc_solver.hip), whose
 // registers stay out of the per-step path's allocation.
 template <int N, int MM, bool DUAL = true>
 __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                 double up_d, double lo_d, double umax, double dmax, double dt,
-                                                double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist)
+                                                double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist,
+                                                double g0)
 {
     constexpr unsigned LD = 2 * N;                       // row length of T
     const bool valid = lane < N, validd = lane < N - 1;
@@ -395,7 +398,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             const double y = valid ? aset_combine<(unsigned)N, ASET_ROWS_LARGE>(Hg, cidF, wF, n_fix, lc, 0.0, 1.0) : 0.0;
             const double pxF = dt * incl_prefix(xF, lane);
             // the system's rows in lanes 0..msys-1: free inputs (their stage), then steering rows (N + stage)
-            if (is_free) { cid_l[rank_f] = lane; val_l[rank_f] = -y; }
+            if (is_free) { cid_l[rank_f] = lane; val_l[rank_f] = -(y + g0); }
             if (is_pre) { cid_l[rank_p] = N + lane; val_l[rank_p] = b_run - vdu - pxF; }
             wave_sync();
             const bool act = lane < msys;
@@ -451,7 +454,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
             // H x for every stage, and with it the multipliers of the fixed inputs:  nu_F = -(H x + P' mu)_F
             const double solc = (act && row_free && ldl.dinv != 0.0) ? sol : 0.0;
             const double hx = valid ? aset_combine<(unsigned)N, ASET_ROWS_LARGE>(Hg, my_cid, solc, n_free, lc, y, 1.0) : 0.0;
-            const double force = hx + dt * incl_suffix((is_pre && muP == muP) ? muP : 0.0, lane);
+            const double force = hx + g0 + dt * incl_suffix((is_pre && muP == muP) ? muP : 0.0, lane);
             res_free = is_free ? force : 0.0;
             nu_u = au != 0 ? -force : 0.0;
             tm = ad != 0 ? (in_run ? -force : muP) : 0.0;
@@ -678,8 +681,8 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
 #define ASET_CLASS_LINKAGE __forceinline__
 #endif
 #define MPC_ASET_ARGS int lane, const double *T, const double *Hm, double Uu, double vdu, double up_d, double lo_d, double umax, \
-                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist
-#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large, hist
+                      double dmax, double dt, double *rec, int au, int ad, int it0, int fl0, double *lds, int cap_large, int hist, double g0
+#define MPC_ASET_PASS lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, au, ad, it0, fl0, lds, cap_large, hist, g0
 template <int N, int MM, int TAG, bool DUAL>
 static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_small(MPC_ASET_ARGS)
 {
@@ -710,12 +713,13 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_huge(MPC_ASET_ARGS)
 
 // One solve: the starting set, then the iteration in the smallest size class that holds the set, moving up a class when
 // the set outgrows it.  warm_mode 0: start from what the unconstrained minimiser violates; 1: from the set in the record
-// (the previous solve of the same closed-loop step); 2: the record is the previous closed-loop step's -- aset_predict
+// (the previous solve of the same closed-loop step; the only start there is when Uu is not the unconstrained minimiser); 2: the record is the previous closed-loop step's -- aset_predict
 // when its history `hist_in` holds two steps, else its set one stage ahead.  Other arguments as aset_body.
 template <int N, int TAG, bool DUAL = true>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
-                                                       double *rec, int warm_mode, double *lds, int cap_large, int hist_in)
+                                                       double *rec, int warm_mode, double *lds, int cap_large, int hist_in,
+                                                       double g0 = 0.0)
 {
     const bool rec_valid = warm_mode != 0;
     constexpr int C0 = aset_class<N>(0), C1 = aset_class<N>(1), C2 = aset_class<N>(2), C3 = aset_class<N>(3), C4 = aset_class<N>(4);
@@ -750,22 +754,22 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     AsetResult r = {0.0, au, ad, 0, 0, ASET_GROW};
     if (!rec_valid && __popcll(__ballot(au != 0)) + __popcll(__ballot(ad != 0)) > ASET_COLD_MAX) return r;   // a large violated set says little about the active one
     int m = aset_system_rows<N, DUAL>(lane, au, ad);
-    if (m <= C0) r = aset_run_small<N, C0, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+    if (m <= C0) r = aset_run_small<N, C0, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist, g0);
     if (C1 > C0 && r.why == ASET_GROW) {
         m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
-        if (m <= C1) r = aset_run_medium<N, C1, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        if (m <= C1) r = aset_run_medium<N, C1, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist, g0);
     }
     if (C2 > C1 && r.why == ASET_GROW) {
         m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
-        if (m <= C2) r = aset_run_large<N, C2, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        if (m <= C2) r = aset_run_large<N, C2, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist, g0);
     }
     if (C3 > C2 && r.why == ASET_GROW) {
         m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
-        if (m <= C3) r = aset_run_full<N, C3, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        if (m <= C3) r = aset_run_full<N, C3, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist, g0);
     }
     if (C4 > C3 && r.why == ASET_GROW) {
         m = aset_system_rows<N, DUAL>(lane, r.au, r.ad);
-        if (m <= C4) r = aset_run_huge<N, C4, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist);
+        if (m <= C4) r = aset_run_huge<N, C4, TAG, DUAL>(lane, T, Hm, Uu, vdu, up_d, lo_d, umax, dmax, dt, rec, r.au, r.ad, r.iters, r.flops, lds, cap_large, hist, g0);
     }
     return r;
 }

@@ -18,29 +18,46 @@
 namespace mpc {
 
 
-constexpr int NL_STAGE_W = 42;   // A[7][5] (columns cos, sin, vy, r, delta; the px and py columns are unit vectors) + b[7]
+// The stage record: A[7][5] (columns cos, sin, vy, r, delta; the px and py columns are unit vectors) + b[7], 42 entries
+// of which 33 are kept -- d (vy, r) / d (cos, sin) and the steering row of A are zero whatever the point (NLMPC.py:108-134).
+// nl_slot: place of entry q = r * 5 + c (A) or 35 + r (b) in the record, -1 for the entries that are not kept.  At 33
+// doubles per stage a wave's LDS is 22.5 KB for N = 50: seven waves per compute unit instead of six.
+constexpr int NL_STAGE_W = 33;
+constexpr int nl_slot(int q)
+{
+    return q < 20 ? q : q < 22 ? -1 : q < 25 ? q - 2 : q < 27 ? -1 : q < 30 ? q - 4 : q < 35 ? -1 : q - 9;
+}
 
 struct NlCoef { double vx, a11, a12, a21, a22, b1, b2; };
 
-// A QP of the SQP iteration whose unconstrained minimiser Uu violates a bound: the active-set solve in its free-input
-// form (H of this scenario and iteration is all it needs), started from the previous QP's set -- the previous closed-loop
-// step's moved one stage ahead (prm.warm_mode 2) or the previous SQP iteration's as it is (1) -- and the interior point
-// for what it hands on, with the back-off of the fixed-model kernels' constrained step (1, 3, 7, 15 QPs of interior
-// point alone after solves that were handed on).  One call site in the SQP loop, a function of its own.
+// A constrained QP of the SQP iteration: the active-set solve in its free-input form (H of this scenario and iteration
+// is all it needs), started from the previous QP's set -- the previous closed-loop step's moved one stage ahead
+// (prm.warm_mode 2) or the previous SQP iteration's as it is (1) -- and the interior point for what it hands on, with the
+// back-off of the fixed-model kernels' constrained step (1, 3, 7, 15 QPs of interior point alone after solves that were
+// handed on).  Called at two places of the SQP loop:
+//   * before the unconstrained minimiser exists, when the previous QP was constrained (try_aset, !allow_ipm): the solve
+//     works about the current iterate Uref with the objective's gradient g0 there, and a QP that ends here never pays
+//     for the factorisation of H;
+//   * after the unconstrained minimiser Uref (g0 = 0) turned out to violate a bound (allow_ipm; try_aset unless the
+//     first call already tried).
+// g: the QP's linear term (the interior point's argument).  A function of its own: its registers stay out of the SQP loop's.
 struct NlQpResult {
     double U, mu, res;
     int iters, status;           // interior-point iterations and status
-    bool warm_valid;
+    bool warm_valid, solved, tried;
 };
 
 template <int N>
 static __device__ __noinline__ __attribute__((cold)) MPC_NOTAIL NlQpResult nl_solve_constrained(IpmParams prm, int lane, const double *Hm, double g,
-                                                                                   double Uu, double vdu, double up_d, double lo_d,
-                                                                                   double *lds, int *as_o, bool try_aset)
+                                                                                   double Uref, double vdref, double g0, double up_d,
+                                                                                   double lo_d, double *lds, int *as_o, bool try_aset,
+                                                                                   bool allow_ipm)
 {
-    NlQpResult out = {0.0, 0.0, 0.0, 0, 0, false};
+    const double Uu = Uref, vdu = vdref;
+    NlQpResult out = {0.0, 0.0, 0.0, 0, 0, false, false, false};
     gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
     if (try_aset && bo) {
+        out.tried = true;
         const double bo0 = bo[0], bo1 = bo[1];
         const int wait = __builtin_amdgcn_readfirstlane((int)bo0);
         if (wait > 0) {
@@ -49,7 +66,7 @@ static __device__ __noinline__ __attribute__((cold)) MPC_NOTAIL NlQpResult nl_so
             // (history word 1: the record is read as the previous solve's set, never extrapolated -- the QPs of one step's
             // SQP iterations are not consecutive steps)
             const AsetResult r = active_set_solve<N, 3, false>(lane, nullptr, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
-                                                               prm.warm_mode, lds, ASET_CAP_LARGE, 1);
+                                                               prm.warm_mode, lds, ASET_CAP_LARGE, 1, g0);
             if (as_o && lane == 0) {
                 atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
                 atomicAdd(&as_o[1], r.iters);
@@ -61,11 +78,13 @@ static __device__ __noinline__ __attribute__((cold)) MPC_NOTAIL NlQpResult nl_so
                 if (streak) bo[0] = (double)((1 << streak) - 1);
             }
             if (r.why == ASET_SOLVED) {
-                out.U = r.U; out.warm_valid = true;
+                out.U = r.U; out.warm_valid = true; out.solved = true;
                 return out;
             }
         }
     }
+    if (!allow_ipm) return out;
+    out.solved = true;
     const IpmResult r = interior_point<N, 3>(prm, lane, Hm, g, up_d, lo_d, (ldouble *)lds);
     out.U = r.U; out.mu = r.mu; out.res = r.res; out.iters = r.iters; out.status = r.status; out.warm_valid = r.warm_valid;
     return out;
@@ -156,11 +175,10 @@ __device__ __forceinline__ void nl_linearise(const double *x, double u, double h
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const double col = fma(h / 6.0, acc[i] + K[i], e[i]);
-            if (sd < 5) st[i * 5 + sd] = col;
-            else st[35 + i] = col;
+            const int q = sd < 5 ? i * 5 + sd : 35 + i;
+            if (nl_slot(q) >= 0) st[nl_slot(q)] = col;
         }
-        if (sd < 5) st[6 * 5 + sd] = e[6];
-        else st[35 + 6] = h;
+        if (sd == 5) st[nl_slot(35 + 6)] = h;                // (the steering row of A is the unit row: not kept)
     }
 }
 
@@ -339,9 +357,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
 #pragma unroll 1
                 for (int k = 1; k <= Ne; k++) {
                     const double *stl = &s_stage[(k - 1) * NL_STAGE_W];
-                    double st[NL_STAGE_W];                // the stage record in one batch of LDS reads (otherwise the
+                    double st[42];                        // the stage record in one batch of LDS reads (otherwise the
 #pragma unroll                                             // scheduler waits for each value where it is used)
-                    for (int q = 0; q < NL_STAGE_W; q++) st[q] = (q < 30 || q >= 35) ? stl[q] : 0.0;
+                    for (int q = 0; q < 42; q++) st[q] = nl_slot(q) >= 0 ? stl[nl_slot(q) >= 0 ? nl_slot(q) : 0] : 0.0;
                     double errk[7];                       // x_k - reference of stage k, read in the same batch
 #pragma unroll
                     for (int c = 0; c < 7; c++) errk[c] = s_x[k * 7 + c];
@@ -408,25 +426,37 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
             if (lane < N) {                         // one divergent region for all N stores, not one per entry
                 store_column<N>(Hw + lane, nt.row);
             }
-            nt.template factor<false>(lane, (ldouble *)s_wv);
-            double Un = nt.solve(gq == 0.0 ? 0.0 : -gq, lane);   // every lane takes part: the rows beyond Ne are unit rows with a zero right-hand side
-            if (!valid) Un = 0.0;
-            const double vd = dt * incl_prefix(Un, lane);
-            bool ok = fabs(Un) <= umax;
-            if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
-            if (!__all(ok)) {
-                nconstr++;
-                // start from the previous QP's interior-point solve: the previous SQP iteration's, or the previous
-                // closed-loop step's moved one stage ahead
-                const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
-                const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm, Ne};
-                const NlQpResult r = nl_solve_constrained<N>(prm, lane, Hw, gq, Un, vd, up_d, lo_d, s_wv,
-                                                             a.as_out ? a.as_out + 6 * (size_t)s : nullptr, a.general_aset != 0 && Ne == N);
-                Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
-                if (r.status) status_max = max(status_max, r.status);
-                warm_ok = (warm_rec != nullptr) && r.warm_valid;
-            } else
-                warm_ok = false;
+            // start from the previous QP's solve: the previous SQP iteration's, or the previous closed-loop step's moved one
+            // stage ahead
+            const int wm = warm_ok ? (sqp == 0 ? 2 : 1) : 0;
+            const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, wm, Ne};
+            int *as_o = a.as_out ? a.as_out + 6 * (size_t)s : nullptr;
+            const bool aset_on = a.general_aset != 0 && Ne == N;
+            double Un = 0.0;
+            bool done = false, tried = false;
+            if (aset_on && warm_ok) {
+                // the previous QP was constrained: this one most likely is, with nearly the same set
+                const double g0 = valid ? g + wr * U : 0.0;                       // gradient of the QP at the current iterate
+                const NlQpResult r = nl_solve_constrained<N>(prm, lane, Hw, gq, U, dt * incl_prefix(U, lane), g0, up_d, lo_d, s_wv, as_o, true, false);
+                tried = r.tried;
+                if (r.solved) { done = true; nconstr++; Un = r.U; warm_ok = r.warm_valid; }
+            }
+            if (!done) {
+                nt.template factor<false>(lane, (ldouble *)s_wv);
+                Un = nt.solve(gq == 0.0 ? 0.0 : -gq, lane);   // every lane takes part: the rows beyond Ne are unit rows with a zero right-hand side
+                if (!valid) Un = 0.0;
+                const double vd = dt * incl_prefix(Un, lane);
+                bool ok = fabs(Un) <= umax;
+                if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
+                if (!__all(ok)) {
+                    nconstr++;
+                    const NlQpResult r = nl_solve_constrained<N>(prm, lane, Hw, gq, Un, vd, 0.0, up_d, lo_d, s_wv, as_o, aset_on && !tried, true);
+                    Un = r.U; mu = r.mu; res = r.res; iters += r.iters;
+                    if (r.status) status_max = max(status_max, r.status);
+                    warm_ok = (warm_rec != nullptr) && r.warm_valid;
+                } else
+                    warm_ok = false;
+            }
             const double step = wave_max(valid ? fabs(Un - U) : 0.0);
             U = valid ? Un : 0.0;
             sqp++;
