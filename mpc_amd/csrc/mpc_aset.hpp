@@ -774,4 +774,48 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     return r;
 }
 
+// One attempt at a QP whose H belongs to this scenario and solve alone (no table): the free-input form about the point
+// Uref (vdref = dt * prefix sum of it) where the objective's gradient is g0 -- the unconstrained minimiser with g0 = 0, or
+// any other point -- started as prm.warm_mode says from the scenario's record prm.warm, with the back-off of the
+// fixed-model kernels' constrained step kept in that record (1, 3, 7, 15 QPs without an attempt after attempts that
+// were handed on).  PREDICT: the record's history may be extrapolated (one QP per closed-loop step), else the record is
+// only read as the previous solve's set.  as_o: the scenario's counters (SolveArgs::as_out) or NULL.
+struct AsetTry {
+    double U;
+    bool solved, tried;
+};
+
+template <int N, int TAG, bool PREDICT>
+__device__ __forceinline__ AsetTry aset_try_general(const IpmParams &prm, int lane, const double *Hm, double Uref, double vdref, double g0,
+                                                    double up_d, double lo_d, double *lds, int *as_o)
+{
+    AsetTry out = {0.0, false, false};
+    aset_gdouble *bo = prm.warm ? (aset_gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
+    if (!bo) return out;
+    out.tried = true;
+    const double bo0 = bo[0], bo1 = bo[1], bo2 = bo[2];                         // one round trip for all
+    const int wait = __builtin_amdgcn_readfirstlane((int)bo0);
+    if (wait > 0) {
+        if (lane == 0) bo[0] = (double)(wait - 1);
+        return out;
+    }
+    const int hist_raw = __builtin_amdgcn_readfirstlane((int)bo2);
+    const int hist = PREDICT ? hist_raw : ((hist_raw & ~3) | min(hist_raw & 3, 1));
+    const AsetResult r = active_set_solve<N, TAG, false>(lane, nullptr, Hm, Uref, vdref, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
+                                                         prm.warm_mode, lds, ASET_CAP_LARGE, hist, g0);
+    if (as_o && lane == 0) {
+        atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
+        atomicAdd(&as_o[1], r.iters);
+        atomicAdd(&as_o[4], (r.flops + 32) >> 6);
+    }
+    if (lane == 0) {
+        const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
+        if ((double)streak != bo1) bo[1] = (double)streak;
+        if (streak) bo[0] = (double)((1 << streak) - 1);
+        if (r.why != ASET_SOLVED && hist_raw != 0) bo[2] = 0.0;                 // the record will be another method's: no history
+    }
+    if (r.why == ASET_SOLVED) { out.U = r.U; out.solved = true; }
+    return out;
+}
+
 }  // namespace mpc

@@ -53,34 +53,15 @@ static __device__ __noinline__ __attribute__((cold)) MPC_NOTAIL NlQpResult nl_so
                                                                                    double lo_d, double *lds, int *as_o, bool try_aset,
                                                                                    bool allow_ipm)
 {
-    const double Uu = Uref, vdu = vdref;
     NlQpResult out = {0.0, 0.0, 0.0, 0, 0, false, false, false};
-    gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
-    if (try_aset && bo) {
-        out.tried = true;
-        const double bo0 = bo[0], bo1 = bo[1];
-        const int wait = __builtin_amdgcn_readfirstlane((int)bo0);
-        if (wait > 0) {
-            if (lane == 0) bo[0] = (double)(wait - 1);
-        } else {
-            // (history word 1: the record is read as the previous solve's set, never extrapolated -- the QPs of one step's
-            // SQP iterations are not consecutive steps)
-            const AsetResult r = active_set_solve<N, 3, false>(lane, nullptr, Hm, Uu, vdu, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
-                                                               prm.warm_mode, lds, ASET_CAP_LARGE, 1, g0);
-            if (as_o && lane == 0) {
-                atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
-                atomicAdd(&as_o[1], r.iters);
-                atomicAdd(&as_o[4], (r.flops + 32) >> 6);
-            }
-            if (lane == 0) {
-                const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
-                if ((double)streak != bo1) bo[1] = (double)streak;
-                if (streak) bo[0] = (double)((1 << streak) - 1);
-            }
-            if (r.why == ASET_SOLVED) {
-                out.U = r.U; out.warm_valid = true; out.solved = true;
-                return out;
-            }
+    if (try_aset) {
+        // (the record is read as the previous solve's set, never extrapolated: the QPs of one step's SQP iterations are
+        // not consecutive steps)
+        const AsetTry r = aset_try_general<N, 3, false>(prm, lane, Hm, Uref, vdref, g0, up_d, lo_d, lds, as_o);
+        out.tried = r.tried;
+        if (r.solved) {
+            out.U = r.U; out.warm_valid = true; out.solved = true;
+            return out;
         }
     }
     if (!allow_ipm) return out;

@@ -204,6 +204,16 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
     return out;
 }
 
+// The same for the kernel that condenses per scenario (no table: H is the scenario's and the step's own): one attempt of
+// the active-set solve in its free-input form about the unconstrained minimiser Uu; the caller's interior point takes
+// what is handed on.  A function of its own, like solve_constrained.
+template <int N>
+static __device__ MPC_CONSTRAINED_LINKAGE AsetTry general_constrained_aset(IpmParams prm, int lane, const double *Hm, double Uu, double vdu,
+                                                                     double up_d, double lo_d, double *lds, int *as_o)
+{
+    return aset_try_general<N, 1, true>(prm, lane, Hm, Uu, vdu, 0.0, up_d, lo_d, lds, as_o);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS per wave: references [3][N+1], speeds [N+1], stage table [N][STAGE_W], parked plant state and coefficients, and
 // for the closed-loop statistics the step's value for each of them (PARK_CL + i: see cl_step)
@@ -621,7 +631,15 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                 bool ok = fabs(Uu) <= umax;
                 if (validd) ok = ok && (vd <= up_d) && (vd >= lo_d);
                 if (__all(ok)) U = Uu;
-                else { constrained = 1; need_ipm = true; }
+                else {
+                    constrained = 1; need_ipm = true;
+                    if (a.general_aset) {
+                        const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
+                        const AsetTry r = general_constrained_aset<N>(prm, lane, Hm, Uu, vd, up_d, lo_d, s_wv,
+                                                                      a.as_out ? a.as_out + 6 * (size_t)s : nullptr);
+                        if (r.solved) { U = r.U; need_ipm = false; solved_warm = true; work_tot += 4; }
+                    }
+                }
             }
             if (need_ipm) {
                 // closed loops start the interior point from the previous step's solve when that step needed one too

@@ -132,7 +132,8 @@ def test_chained_rebalanced_run_equals_step_by_step(model, N, Tf):
     assert torch.equal(a.state, b.state) and torch.equal(a.state, xs_b[-1])
     assert torch.equal(a.lap, b.lap) and torch.equal(a.prev_progress, b.prev_progress)
     assert torch.equal(it_a, b.iters.to(torch.int64)) and torch.equal(st_a, b.status)
-    assert int(it_a.max()) > (4 if model == "L" else 1) * max(1, int(it_a.min()))     # the work is uneven, so the order is not the identity
+    if model == "L":       # the interior-point work is uneven, so the order is not the identity (the LPV and NL kernels
+        assert int(it_a.max()) > 4 * max(1, int(it_a.min()))      # finish nearly every QP in the active-set attempt)
     # the second call starts from the order the first one left
     n2 = 1100 if model == "L" else 130         # L: longer than one chunk, so a chain of two launches
     us_a2 = torch.stack([a.step().clone() for _ in range(n2)])
