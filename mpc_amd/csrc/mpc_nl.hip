@@ -419,8 +419,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_mpc_nl(const DevCfg cfg, const Solv
                 // the previous QP was constrained: this one most likely is, with nearly the same set
                 const double g0 = valid ? g + wr * U : 0.0;                       // gradient of the QP at the current iterate
                 const NlQpResult r = nl_solve_constrained<N>(prm, lane, Hw, gq, U, dt * incl_prefix(U, lane), g0, up_d, lo_d, s_wv, as_o, true, false);
-                tried = r.tried;
-                if (r.solved) { done = true; nconstr++; Un = r.U; warm_ok = r.warm_valid; }
+                tried = __builtin_amdgcn_readfirstlane((int)r.tried) != 0;      // (flags come back in vector registers)
+                if (__builtin_amdgcn_readfirstlane((int)r.solved)) { done = true; nconstr++; Un = r.U; warm_ok = true; }
             }
             if (!done) {
                 nt.template factor<false>(lane, (ldouble *)s_wv);

@@ -637,7 +637,8 @@ __global__ __launch_bounds__(GENERAL ? WAVE : FIXED_WPB * WAVE, 2) void k_mpc(co
                         const IpmParams prm = {dt, umax, dmax, cfg.tol_mu, cfg.tol_res, cfg.max_iter, warm_rec, warm_ok ? 2 : 0, N};
                         const AsetTry r = general_constrained_aset<N>(prm, lane, Hm, Uu, vd, up_d, lo_d, s_wv,
                                                                       a.as_out ? a.as_out + 6 * (size_t)s : nullptr);
-                        if (r.solved) { U = r.U; need_ipm = false; solved_warm = true; work_tot += 4; }
+                        // (the flag comes back in a vector register: made uniform here, the branch is a scalar one)
+                        if (__builtin_amdgcn_readfirstlane((int)r.solved)) { U = r.U; need_ipm = false; solved_warm = true; work_tot += 4; }
                     }
                 }
             }

@@ -19,10 +19,19 @@ while i < len(lines):
         label = l.split(":")[0]
         j = i + 1
         pre = []
+        saved_here = set()          # EXEC masks saved inside this block: their restores pair up here, they are no join prologue
         while j < len(lines):
             t = lines[j].split(";")[0].strip()
             if re.match(r"^\.LBB\d+_\d+:", lines[j]) or re.match(r"s_c?branch|s_endpgm", t):
                 break
+            ms = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\])", t)
+            if ms:
+                saved_here.add(ms.group(1))
+            mr = re.match(r"s_or_b64 exec, exec, (s\[\d+:\d+\])", t)
+            if mr and mr.group(1) in saved_here:
+                saved_here.discard(mr.group(1))
+                j += 1
+                continue
             if re.match(r"s_or_b64 exec, exec,", t):
                 # register saves only: other vector code ahead of the restore is the tail of the region itself
                 vec = [p for p in pre if re.match(r"v_accvgpr_write_b32|scratch_store", p)]
