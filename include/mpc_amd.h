@@ -96,14 +96,19 @@ typedef struct mpc_config {
                           * N x N problem; MPC_LAYOUT_LANE: one lane per scenario, stage-wise Riccati interior point
                           * (kinds L / OFL / LPV; not for mpc_ofl_closed_loop_run).  AUTO = LANE where it is the faster one:
                           * kinds L and LPV at horizons other than 10, 20, 30, 40, 50, 64 with B >= 2048; else WAVE */
-    int qp_method;       /* how a solve whose unconstrained minimiser violates a bound is finished.  MPC_QP_AUTO: with the
-                          * fixed-model cache on (mpc_condense_fixed) the active bounds are found by a primal-dual active-set
-                          * iteration started from the previous closed-loop step's set and the multipliers come from a small
-                          * system built from the cached inv(H); the result is refined through that system and certified
-                          * by the size of the refinement, and whatever does not end that way (large or cycling sets) goes
-                          * to the interior point.  Both give the unique minimiser (they agree to the solver tolerances,
-                          * not bit for bit).  MPC_QP_INTERIOR_POINT: interior point only.  MPC_QP_ACTIVE_SET: the same as
-                          * AUTO (kept for callers written when mpc_ofl_closed_loop_run needed it to use the method) */
+    int qp_method;       /* how a solve whose unconstrained minimiser violates a bound is finished.  MPC_QP_AUTO: the
+                          * active bounds are found by an active-set iteration started from a prediction of the set (the
+                          * previous closed-loop steps' sets; for the NL kind also the previous SQP iteration's), each
+                          * iteration solving the smaller of two small systems -- in the multipliers, built from the
+                          * cached inv(H) (fixed-model cache on, mpc_condense_fixed), or in the inputs the set leaves free,
+                          * built from H itself (also without the cache: wave layout at the horizons 10, 20, 30, 40, 50,
+                          * 64, kinds L / OFL / LPV in closed loops and NL); the result is refined through that system and
+                          * certified by the size of the refinement, and whatever does not end that way (large or cycling
+                          * sets) goes to the interior point.  Both give the unique minimiser (they agree to the solver
+                          * tolerances, not bit for bit).  MPC_QP_INTERIOR_POINT: interior point only.
+                          * MPC_QP_ACTIVE_SET: the same as AUTO (kept for callers written when mpc_ofl_closed_loop_run
+                          * needed it to use the method).  The lane layout and horizons without a register
+                          * instantiation always use the interior point. */
     int emulate_acados;  /* 0 (default): every solve returns the unique minimiser of the problem the reference poses.
                           * 1 (kinds L, OFL, LPV at the horizons 10, 20, 30, 40, 50, 64; wave layout): the solve goes
                           * through what the reference's solver options (LMPC2.py:262-288: SQP, EXACT Hessian,

@@ -470,6 +470,7 @@ class NLOcp(_CondensedMpc):
         cfg.sqp_tol, cfg.sqp_max_iter = self._sqp
         cfg.ipm_cold_start = self._ipm_cold
         cfg.step_ramp_length = self._step_ramp
+        cfg.qp_method = self._qp_method              # "interior_point": no active-set attempt at the QPs of the SQP iterations
         return cfg
 
     def stability(self):
