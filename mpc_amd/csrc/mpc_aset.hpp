@@ -44,6 +44,13 @@ typedef __attribute__((address_space(3))) int aset_lint;
 constexpr int ASET_MAX_ITER = ASET_MAX_ITER_N;       // size classes up to 32
 constexpr int ASET_CAP_LARGE = 6;       // the larger classes; the caller passes its own (`cap_large`): the output-feedback
 constexpr int ASET_CAP_LARGE_NOISY = 4; // loop, whose sets jump with the estimate's noise, hands on earlier (measured)
+// After a solve that was handed on the next 2^min(failures in a row, ASET_BACKOFF_LOG2) - 1 constrained steps of the
+// scenario skip the method.  0 = never wait: with the free-input form an attempt costs a few small systems, far less than
+// the interior-point solve it may save (measured on the noisy output-feedback workload, where 4 in 10 attempts are
+// handed on: 9.6 -> 11.8 M scenario-steps/s without the wait; 62 -> 67 M on the skidpad driver window).
+#ifndef ASET_BACKOFF_LOG2
+#define ASET_BACKOFF_LOG2 0
+#endif
 constexpr int ASET_COLD_MAX = 16;      // largest violated set a solve without a previous set starts from
 // sizes of the certificate's corrections relative to the input bound: a first correction below EARLY is taken as final
 // (what is left after it is smaller by the accuracy of the cached inverse), a later one has to come out below TOL
@@ -536,7 +543,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         AT(5);
     }
     out.au = au; out.ad = ad;
-    if (!converged) return out;
+    if (!converged) { AT_COUNT(21); return out; }
     out.why = ASET_UNCERTIFIED;
 
     // Refinement and certificate.  What the point misses its active bounds by (the rounding of the factorisation and of
@@ -641,7 +648,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         AT_COUNT(17);
     }
     AT(6);
-    if (!certified) return out;
+    if (!certified) { AT_COUNT(22); return out; }
     // the refined point against the bounds and the signs once more, at the accuracy of the certificate
     {
         const double force = nu_u + dt * incl_suffix(validd ? nu_d : 0.0, lane);
@@ -650,7 +657,7 @@ __device__ __forceinline__ AsetResult aset_body(int lane, const double *T, const
         bool good = true;
         if (valid) good = fabs(U) <= umax * (1.0 + 1e-11) && nu_u * (double)au >= -1e-11 * scale;
         if (validd) good = good && vd <= up_d + 1e-11 * dmax && vd >= lo_d - 1e-11 * dmax && nu_d * (double)ad >= -1e-11 * scale;
-        if (!__all(good)) return out;
+        if (!__all(good)) { AT_COUNT(23); return out; }
     }
     U = valid ? fmin(fmax(U, -umax), umax) : 0.0;
     if (rec && valid) {
@@ -777,8 +784,7 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
 // One attempt at a QP whose H belongs to this scenario and solve alone (no table): the free-input form about the point
 // Uref (vdref = dt * prefix sum of it) where the objective's gradient is g0 -- the unconstrained minimiser with g0 = 0, or
 // any other point -- started as prm.warm_mode says from the scenario's record prm.warm, with the back-off of the
-// fixed-model kernels' constrained step kept in that record (1, 3, 7, 15 QPs without an attempt after attempts that
-// were handed on).  PREDICT: the record's history may be extrapolated (one QP per closed-loop step), else the record is
+// fixed-model kernels' constrained step kept in that record (ASET_BACKOFF_LOG2; off by default).  PREDICT: the record's history may be extrapolated (one QP per closed-loop step), else the record is
 // only read as the previous solve's set.  as_o: the scenario's counters (SolveArgs::as_out) or NULL.
 struct AsetTry {
     double U;
@@ -811,7 +817,7 @@ __device__ __forceinline__ AsetTry aset_try_general(const IpmParams &prm, int la
     if (lane == 0) {
         const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
         if ((double)streak != bo1) bo[1] = (double)streak;
-        if (streak) bo[0] = (double)((1 << streak) - 1);
+        if (streak) bo[0] = (double)((1 << min(streak, ASET_BACKOFF_LOG2)) - 1);
         if (r.why != ASET_SOLVED && hist_raw != 0) bo[2] = 0.0;                 // the record will be another method's: no history
     }
     if (r.why == ASET_SOLVED) { out.U = r.U; out.solved = true; }

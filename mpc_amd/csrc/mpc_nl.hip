@@ -33,8 +33,7 @@ struct NlCoef { double vx, a11, a12, a21, a22, b1, b2; };
 // A constrained QP of the SQP iteration: the active-set solve in its free-input form (H of this scenario and iteration
 // is all it needs), started from the previous QP's set -- the previous closed-loop step's moved one stage ahead
 // (prm.warm_mode 2) or the previous SQP iteration's as it is (1) -- and the interior point for what it hands on, with the
-// back-off of the fixed-model kernels' constrained step (1, 3, 7, 15 QPs of interior point alone after solves that were
-// handed on).  Called at two places of the SQP loop:
+// back-off of the fixed-model kernels' constrained step (off by default).  Called at two places of the SQP loop:
 //   * before the unconstrained minimiser exists, when the previous QP was constrained (try_aset, !allow_ipm): the solve
 //     works about the current iterate Uref with the objective's gradient g0 there, and a QP that ends here never pays
 //     for the factorisation of H;

@@ -155,9 +155,9 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
     ConstrainedResult out = {0.0, 0.0, 0.0, 0, 0, 0, false};
     AT_BEGIN();
     AT_COUNT(18);
-    // Back-off: a scenario whose active-set solves keep being handed on (the output-feedback loop on its way to the step:
-    // as many active bounds as inputs) tries the method again only after 1, 3, 7, 15 steps of interior point alone.  The
-    // two counters (steps to wait, failures in a row) travel in the scenario's record behind its validity flag.
+    // Back-off (ASET_BACKOFF_LOG2 in mpc_aset.hpp; off by default): a scenario whose active-set solves keep being handed
+    // on would try the method again only after 1, 3, 7, ... steps of interior point alone.  The two counters (steps to
+    // wait, failures in a row) travel in the scenario's record behind its validity flag.
     gdouble *bo = prm.warm ? (gdouble *)prm.warm + 5 * WAVE + 1 : nullptr;
     double bo0 = 0.0, bo1 = 0.0, bo2 = 0.0;
     if (bo) { bo0 = bo[0]; bo1 = bo[1]; bo2 = bo[2]; }                          // one round trip for all (bo[2]: the history word of the active-set solve)
@@ -185,7 +185,7 @@ static __device__ MPC_CONSTRAINED_LINKAGE ConstrainedResult solve_constrained(Ip
         if (bo && lane == 0) {
             const int streak = r.why == ASET_SOLVED ? 0 : min((int)bo1 + 1, 4);
             if ((double)streak != bo1) bo[1] = (double)streak;
-            if (streak) bo[0] = (double)((1 << streak) - 1);
+            if (streak) bo[0] = (double)((1 << min(streak, ASET_BACKOFF_LOG2)) - 1);
             if (r.why != ASET_SOLVED && hist != 0) bo[2] = 0.0;          // the record will be the interior point's: no history
         }
         if (r.why == ASET_SOLVED) {
