@@ -721,8 +721,9 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_huge(MPC_ASET_ARGS)
 // One solve: the starting set, then the iteration in the smallest size class that holds the set, moving up a class when
 // the set outgrows it.  warm_mode 0: start from what the unconstrained minimiser violates; 1: from the set in the record
 // (the previous solve of the same closed-loop step; the only start there is when Uu is not the unconstrained minimiser); 2: the record is the previous closed-loop step's -- aset_predict
-// when its history `hist_in` holds two steps, else its set one stage ahead.  Other arguments as aset_body.
-template <int N, int TAG, bool DUAL = true>
+// when its history `hist_in` holds two steps, else its set one stage ahead.  PREDICT = false compiles the prediction out (callers that never have two consecutive steps in the
+// record).  Other arguments as aset_body.
+template <int N, int TAG, bool DUAL = true, bool PREDICT = true>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
                                                        double *rec, int warm_mode, double *lds, int cap_large, int hist_in,
@@ -737,7 +738,7 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
     const bool chain = warm_mode == 2 && (hist_in & 3) != 0;
     const int cur = (hist_in >> 2) & 1;
     const int hist = chain ? (min((hist_in & 3) + 1, 2) | ((cur ^ 1) << 2)) : 1;
-    if (chain && (hist_in & 3) == 2) {
+    if (PREDICT && chain && (hist_in & 3) == 2) {
         const aset_gdouble *hc = (const aset_gdouble *)rec + ASET_HIST_BASE + cur * ASET_HIST_SLOT;
         const aset_gdouble *hp = (const aset_gdouble *)rec + ASET_HIST_BASE + (cur ^ 1) * ASET_HIST_SLOT;
         au = aset_predict(hc, hc + 2 * WAVE, hp, hp + 2 * WAVE, lane, N - 1);
@@ -807,7 +808,7 @@ __device__ __forceinline__ AsetTry aset_try_general(const IpmParams &prm, int la
     }
     const int hist_raw = __builtin_amdgcn_readfirstlane((int)bo2);
     const int hist = PREDICT ? hist_raw : ((hist_raw & ~3) | min(hist_raw & 3, 1));
-    const AsetResult r = active_set_solve<N, TAG, false>(lane, nullptr, Hm, Uref, vdref, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
+    const AsetResult r = active_set_solve<N, TAG, false, PREDICT>(lane, nullptr, Hm, Uref, vdref, up_d, lo_d, prm.umax, prm.dmax, prm.dt, prm.warm,
                                                          prm.warm_mode, lds, ASET_CAP_LARGE, hist, g0);
     if (as_o && lane == 0) {
         atomicAdd(&as_o[r.why == ASET_SOLVED ? 0 : r.why == ASET_GROW ? 2 : 3], 1);
