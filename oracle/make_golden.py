@@ -64,7 +64,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         dyn = Dynamics(0.01)
     rec["Cf_Cr"] = np.array([dyn.Cf, dyn.Cr])
-    # the known-answer case of the survey: dt=0.01, x=[15,0.1,1,0,8,0,0,0], u=0.5
+    # a known-answer case: dt=0.01, x=[15,0.1,1,0,8,0,0,0], u=0.5
     rec["kat_x1"] = dyn.rk4_integraton(np.array([15, 0.1, 1.0, 0, 8.0, 0, 0, 0]), 0.5)
     save("plant", **rec)
 
