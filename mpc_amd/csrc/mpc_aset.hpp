@@ -720,9 +720,10 @@ static __device__ ASET_CLASS_LINKAGE AsetResult aset_run_huge(MPC_ASET_ARGS)
 
 // One solve: the starting set, then the iteration in the smallest size class that holds the set, moving up a class when
 // the set outgrows it.  warm_mode 0: start from what the unconstrained minimiser violates; 1: from the set in the record
-// (the previous solve of the same closed-loop step; the only start there is when Uu is not the unconstrained minimiser); 2: the record is the previous closed-loop step's -- aset_predict
-// when its history `hist_in` holds two steps, else its set one stage ahead.  PREDICT = false compiles the prediction out (callers that never have two consecutive steps in the
-// record).  Other arguments as aset_body.
+// (the previous solve of the same closed-loop step); 2: the record is the previous closed-loop step's -- aset_predict
+// when its history `hist_in` holds two steps, else its set one stage ahead.  When Uu is not the unconstrained minimiser
+// (g0 != 0) only the starts from a record make sense.  PREDICT = false compiles the prediction out (callers that never
+// have two consecutive steps in the record).  Other arguments as aset_body.
 template <int N, int TAG, bool DUAL = true, bool PREDICT = true>
 __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T, const double *Hm, double Uu, double vdu,
                                                        double up_d, double lo_d, double umax, double dmax, double dt,
@@ -785,8 +786,9 @@ __device__ __forceinline__ AsetResult active_set_solve(int lane, const double *T
 // One attempt at a QP whose H belongs to this scenario and solve alone (no table): the free-input form about the point
 // Uref (vdref = dt * prefix sum of it) where the objective's gradient is g0 -- the unconstrained minimiser with g0 = 0, or
 // any other point -- started as prm.warm_mode says from the scenario's record prm.warm, with the back-off of the
-// fixed-model kernels' constrained step kept in that record (ASET_BACKOFF_LOG2; off by default).  PREDICT: the record's history may be extrapolated (one QP per closed-loop step), else the record is
-// only read as the previous solve's set.  as_o: the scenario's counters (SolveArgs::as_out) or NULL.
+// fixed-model kernels' constrained step kept in that record (ASET_BACKOFF_LOG2; off by default).  PREDICT: the record's
+// history may be extrapolated (one QP per closed-loop step), else the record is only read as the previous solve's set.
+// as_o: the scenario's counters (SolveArgs::as_out) or NULL.
 struct AsetTry {
     double U;
     bool solved, tried;
